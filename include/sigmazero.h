@@ -1,0 +1,155 @@
+/* sigmazero.h — C ABI of the MI355X-native batched MCTS self-play engine.
+ *
+ * The reference (DidItWork/Sigma-Zero) has NO native/FFI layer: its boundary for this path is the
+ * Python call surface.  This header is therefore the boundary a maintainer binds
+ * from Python with ctypes (INTEGRATION.md shows the stub); every entry point names the reference
+ * code it replaces.  Plain pointers and sizes only — no torch types.
+ *
+ * Conventions: every function returns SZ_OK (0) or a negative SZ_ERR_*; the engine owns all of its
+ * device memory; tensors handed in by pointer stay owned by the caller; all device work is enqueued
+ * on the caller's stream (pass torch.cuda.current_stream().cuda_stream); one engine per GPU per
+ * process; not thread-safe.
+ */
+#ifndef SIGMAZERO_H
+#define SIGMAZERO_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZ_RING 256              /* per-game position history kept for repetition / history planes */
+#define SZ_PLANES 119            /* chess_tensor.py:31-35  M*T+L = 14*8+7 */
+#define SZ_ACTIONS 4672          /* 73*8*8, chess_tensor.py:197 */
+#define SZ_MAX_MOVES 218
+#define SZ_POS_BYTES 80
+
+enum {
+    SZ_OK = 0,
+    SZ_ERR_INVALID = -1,         /* bad argument / illegal move (ValueError("Invalid move"), chess_tensor.py:91-92) */
+    SZ_ERR_HIP = -2,             /* a HIP runtime call failed */
+    SZ_ERR_CAPACITY = -3,        /* a board ran out of child slots (edges_per_board too small) */
+    SZ_ERR_NO_DEVICE = -4,       /* no MI355X visible: the product path never falls back to the CPU */
+    SZ_ERR_STATE = -5,           /* call sequence violated (e.g. step before begin) */
+    SZ_ERR_ZERO_VISITS = -6      /* num_searches == 1: the reference raises ZeroDivisionError (mcts.py:118-120) */
+};
+
+enum { SZ_PLANES_F32 = 0, SZ_PLANES_BF16 = 1 };
+
+/* ------------------------------------------------------------------ engine (HIP, gfx950) */
+
+typedef struct sz_engine sz_engine;
+
+typedef struct sz_config {
+    int32_t n_boards;            /* concurrent self-play boards on this GPU */
+    int32_t num_searches;        /* args['num_searches'], mcts.py:49 */
+    float   c_puct;              /* args['C'], mctsnode.py:37 */
+    int32_t learning;            /* search(..., learning=...), mcts.py:91 */
+    float   noise_value;         /* value of the degenerate Dirichlet draw of mcts.py:93 (1-2^-24 under torch 2.10) */
+    int32_t chess960;            /* boards spell castling king-takes-rook (chess.Board(chess960=True)) */
+    int32_t edges_per_board;     /* child slots per board per search; 0 = num_searches*64+256 */
+    int32_t planes_dtype;        /* SZ_PLANES_F32 / SZ_PLANES_BF16: element type of the network input */
+    int32_t device;              /* HIP device ordinal */
+} sz_config;
+
+typedef struct sz_stats {
+    uint64_t simulations;        /* executions of the mcts.py:49 loop body, all boards */
+    uint64_t expansions;         /* non-terminal leaves evaluated by the network (mcts.py:66-102) */
+    uint64_t terminal_hits;      /* simulations that ended in a terminal leaf (mcts.py:104-106) */
+    uint64_t sum_depth;          /* sum of leaf depths (edges from the root) */
+    uint64_t sum_children;       /* sum of K over expansions */
+    uint64_t max_edges_used;     /* high-water mark of child slots on any board */
+    int32_t  boards_pending;     /* boards waiting for a network evaluation */
+    int32_t  boards_done;        /* boards whose search finished */
+    int32_t  boards_error;       /* boards with a sticky error flag */
+    int32_t  first_error;        /* SZ_ERR_* of the first failing board, or 0 */
+} sz_stats;
+
+/* MCTS0.__init__ (mcts.py:30-37): allocate the SoA node store for n_boards trees. */
+int sz_create(const sz_config* cfg, sz_engine** out);
+int sz_destroy(sz_engine* e);
+
+/* ChessTensor.__init__/start_board (chess_tensor.py:31-35,65-86) for every board with active[b] != 0
+ * (NULL = all): scharnagl[b] >= 0 -> Board.from_chess960_pos(n), < 0 -> chess.Board().
+ * Host arrays. */
+int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, void* stream);
+
+/* Put an arbitrary live game on one board: `ring` is the SZ_RING*SZ_POS_BYTES history exported by
+ * szh_export (the root game object of mcts.py:43, which search() uses un-copied). */
+int sz_upload_game(sz_engine* e, int32_t board, const void* ring, int32_t ply, void* stream);
+/* mark boards (in)active for the next searches; host array of n_boards bytes */
+int sz_set_active(sz_engine* e, const uint8_t* active, void* stream);
+
+/* First half of MCTS0.search (mcts.py:43-75): create the roots (visit_count = 1), test them for
+ * termination, and write the network input of every root into planes_dev [n_boards,119,8,8]. */
+int sz_search_begin(sz_engine* e, void* planes_dev, void* stream);
+
+/* One lock-step iteration over all boards: consume model(x, inference=True) for the pending leaves
+ * (policy_dev [n_boards,4672] f32 probabilities, value_dev [n_boards] f32) = masked renormalise,
+ * noise mix, Node.expand, Node.backpropagate (mcts.py:77-109, mctsnode.py:39-63); then run
+ * Node.select (mctsnode.py:23-37) down to the next leaf of each board, play the move
+ * (mcts.py:57-59), test termination (terminal leaves are backed up on the spot and selection
+ * repeats), and encode the next network input into planes_dev. */
+int sz_search_step(sz_engine* e, const float* policy_dev, const float* value_dev, void* planes_dev, void* stream);
+
+/* Counters (synchronises the stream). */
+int sz_get_stats(sz_engine* e, sz_stats* out, void* stream);
+
+/* mcts.py:113-122 readout: for each board the root children in ascending action-index order.
+ * Device pointers: action [n_boards,218] int32, visits [n_boards,218] int32, n_child [n_boards] int32;
+ * optional (may be NULL) prior [n_boards,218] f32 and value_sum [n_boards,218] f64. */
+int sz_root_children(sz_engine* e, int32_t* action_dev, int32_t* visits_dev, int32_t* n_child_dev,
+                     float* prior_dev, double* value_sum_dev, void* stream);
+
+/* sim.py:68-76: sample a move per board from the visit distribution exactly like
+ * np.random.choice(keys, p=visits/sum) given the uniform it draws (uniforms_dev [n_boards] f64),
+ * record the training sample of this ply, play the move into the board's game and test
+ * board.is_game_over() (sim.py:46). */
+int sz_play(sz_engine* e, const double* uniforms_dev, void* stream);
+
+/* Copy this ply's training records to host arrays (synchronises; any pointer may be NULL):
+ *  packed_planes [n_boards,119,8] uint8   root get_representation(), bit j of byte = column j
+ *                                         (the (119,8) format of generate_training_supervised.py:91)
+ *  action/visits [n_boards,218] int32, n_child [n_boards] int32        sim.py:72 'actions'
+ *  colour [n_boards] uint8 (board.turn at the root, sim.py:73), chosen [n_boards] int32 (action index),
+ *  game_over [n_boards] uint8, result [n_boards] int8 (+1 = '1-0', -1 = '0-1', 0 draw; sim.py:86-92),
+ *  active [n_boards] uint8 (whether the record is valid for this ply). */
+int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t* visits, int32_t* n_child,
+                 uint8_t* colour, int32_t* chosen, uint8_t* game_over, int8_t* result, uint8_t* active, void* stream);
+
+/* test / debug readback of the pending leaves: legal-move mask [n_boards,73] uint64 (bit v of word p =
+ * action p*64+v), leaf depth, node count, edge count, status per board (host pointers, may be NULL). */
+int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges,
+                     int32_t* status, void* stream);
+/* copy one board's current game position record (SZ_POS_BYTES) to the host */
+int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, void* stream);
+
+const char* sz_error_string(int code);
+int sz_device_count(void);
+
+/* ------------------------------------------------------------------ host mirror (no GPU) */
+
+/* One game = the reference's ChessTensor object (chess_tensor.py:30-188), rules from the same
+ * __host__ __device__ code the kernels run.  Piece codes follow python-chess: N=2 B=3 R=4 Q=5. */
+typedef struct szh_game szh_game;
+
+szh_game* szh_game_new(int chess960, int scharnagl);                 /* ChessTensor(chess960) ; :69 / :71 */
+szh_game* szh_game_from_fen(const char* fen, int chess960);
+szh_game* szh_game_copy(const szh_game* g);                          /* copy.deepcopy(game), mcts.py:58 */
+void      szh_game_free(szh_game* g);
+int  szh_legal_actions(const szh_game* g, int32_t* idx);             /* actionsToTensor(get_valid_moves()) support, ascending */
+int  szh_action_to_move(const szh_game* g, int idx, int32_t* from, int32_t* to, int32_t* promo);  /* tensorToAction, :309-410 */
+int  szh_move_to_action(int from, int to, int promo, int white);    /* actionToTensor, :221-306 */
+int  szh_push_action(szh_game* g, int idx);                          /* move_piece, :88-129 */
+int  szh_push_move(szh_game* g, int from, int to, int promo);
+void szh_status(const szh_game* g, int32_t* out12);
+void szh_planes(const szh_game* g, uint8_t* out /* 119*64 */);        /* get_representation, :131-142 */
+uint64_t szh_perft(szh_game* g, int depth);
+void szh_bitboards(const szh_game* g, uint64_t* out10);
+int  szh_export(const szh_game* g, void* ring_out, int32_t* ply, int32_t* chess960);
+int  szh_is_chess960(const szh_game* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,785 @@
+// sz_engine.hip — batched MCTS self-play engine for MI355X (gfx950), hand-written HIP.
+//
+// Replaces, for thousands of concurrent boards, the per-game Python tree of the reference:
+//   MCTS0.search            /root/reference/mcts.py:39-122
+//   Node.select/get_ucb     /root/reference/mctsnode.py:23-37
+//   Node.expand             /root/reference/mctsnode.py:39-54
+//   Node.backpropagate      /root/reference/mctsnode.py:56-63
+//   ChessTensor.move_piece / get_representation / get_value_and_terminated
+//                           /root/reference/chess_tensor.py:88-172
+//   actionsToTensor / tensorToAction (legal-move mask, child order)  chess_tensor.py:190-410
+//   play_game's sampling + bookkeeping                               /root/reference/sim.py:46-97
+//
+// Execution model: ONE WAVEFRONT (64 lanes) OWNS ONE BOARD.
+//   * tree = flat SoA in HBM per board: EdgeStat{W f64, N i32, P f32} (16 B, one dwordx4 per child,
+//     a node's children are contiguous => coalesced span reads), EdgeMeta (16 B, read only for the
+//     selected child), position records (80 B) for visited nodes only;
+//   * select: lanes = children, UCB in the reference's exact fp32 op order, wave64 butterfly argmax
+//     with lowest-index tie-break (torch.argmax semantics);
+//   * move generation: lanes = squares (sz_chess.h), 73 ballots produce the legal-move mask directly
+//     in action-index order, so children come out sorted with prefix popcounts (no sort);
+//   * expand: masked renormalise with a fixed summation order (lane-strided partials + xor butterfly),
+//     bit-identical to oracle/oc_mcts.c; backprop: the descent path sits in LDS, one lane per level,
+//     no atomics (one leaf per board per step) => bitwise deterministic;
+//   * encode: history bitboards staged in LDS, every lane emits one 8-cell row per store (16/32 B).
+// No MFMA here by design: this is latency/HBM-bound integer work; the network is the MFMA consumer.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "sz_chess.h"
+#include "../../include/sigmazero.h"
+
+// ------------------------------------------------------------------------------------------------
+// device data
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) EdgeStat { double W; int N; float P; };
+struct alignas(16) EdgeMeta { int first; int node; unsigned short n; unsigned short action; signed char term; signed char tval; unsigned short pad; };
+
+enum { ST_ACTIVE = 1, ST_PENDING = 2, ST_DONE = 4, ST_GAMEOVER = 8, ST_ERROR = 16, ST_SEARCHING = 32 };
+
+struct alignas(16) Ctl {
+    int status, n_nodes, n_edges, sims_done;
+    int pend_node, pend_depth, game_ply, err;
+    unsigned long long n_expand, n_term, sum_depth, sum_k;
+    int max_edges, game_result, pad0, pad1;
+};
+
+struct View {
+    int B, S, n_cap, e_cap, p_cap, learning, chess960, planes_dtype;
+    float c_puct, noise;
+    SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
+    // per-ply training record
+    uint8_t* rec_planes; int* rec_action; int* rec_visits; int* rec_nchild; uint8_t* rec_colour; int* rec_chosen;
+    uint8_t* rec_over; int8_t* rec_result; uint8_t* rec_active;
+};
+
+#define PMASK_STRIDE 80     // u64 words per board (73 used)
+#define LDS_HIST_WORDS 64   // 8 history slots x 8 words
+#define LDS_MASK_WORDS 80
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ u64 uni64(u64 x) {
+    u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ SzPos load_pos(const SzPos* ptr) {
+    SzPos p = *ptr;
+    for (int k = 0; k < 6; k++) p.pc[k] = uni64(p.pc[k]);
+    p.white = uni64(p.white); p.meta = uni64(p.meta); p.key = uni64(p.key); p.castling = uni64(p.castling);
+    return p;
+}
+__device__ __forceinline__ float wave_sum_butterfly(float v) {
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+// lane-indexed ballot (bit v = view square v) -> real-square bitboard
+__device__ __forceinline__ u64 view_to_squares(u64 m, int white) {
+    return white ? __builtin_bswap64(m) : __builtin_bswap64(sz_brev(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node.get_ucb (mctsnode.py:33-37) in torch's float32 operation order; see oracle/oc_mcts.c:oc_ucb.
+// Compiled with -ffp-contract=off: each operator is one IEEE rounding.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ucb_value(int vc, double wsum, float prior, float sqrt_parent, float c) {
+    float vsum = (float)wsum;
+    float t1 = (float)vc + 1e-6f;
+    float q = 1.0f - ((vsum / t1) + 1.0f) / 2.0f;
+    float r = 1.0f / (float)(vc + 1);
+    float u = ((r * sqrt_parent) * c) * prior;
+    return q + u;
+}
+
+struct BoardPtrs {
+    SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
+};
+__device__ __forceinline__ BoardPtrs board_ptrs(const View& v, int b) {
+    BoardPtrs p;
+    p.npos = v.npos + (size_t)b * v.n_cap;
+    p.ring = v.ring + (size_t)b * SZ_RING;
+    p.es = v.es + (size_t)b * v.e_cap;
+    p.em = v.em + (size_t)b * v.e_cap;
+    p.gpath = v.gpath + (size_t)b * v.p_cap;
+    p.pmask = v.pmask + (size_t)b * PMASK_STRIDE;
+    p.ctl = v.ctl + b;
+    return p;
+}
+
+// position `j` plies before a node at tree depth D whose root sits at game ply root_ply
+__device__ __forceinline__ const SzPos* ancestor_ptr(const BoardPtrs& bp, const int* path, int D, int root_ply, int j) {
+    int dj = D - j;
+    if (dj >= 0) return bp.npos + bp.em[path[dj]].node;
+    int ply = root_ply + dj;
+    if (ply < 0 || -dj >= SZ_RING) return nullptr;
+    return bp.ring + (ply & (SZ_RING - 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Move generation for position X (uniform), one lane per square.  Fills mask[0..72] in LDS and
+// returns n_legal / ep_legal / checkers (uniform).
+// ------------------------------------------------------------------------------------------------
+__device__ void wave_movegen(const SzPos& X, int chess960, u64* mask_lds, int& n_legal, int& ep_legal, u64& checkers) {
+    const int lane = lane_id();
+    SzInfo I = sz_info(X);
+    const int s = lane ^ sz_view_flip(I.white);
+    const bool need = (I.need >> s) & 1;
+    bool att = false;
+    if (need) att = sz_danger_at(X, I, s);
+    u64 danger = view_to_squares(__ballot(att), I.white);
+    u64 T;
+    if (s == I.ksq) T = sz_king_targets(X, I, danger, chess960);
+    else T = sz_piece_targets(X, I, s);
+    const bool is_pawn = (X.pc[SZ_P] >> s) & 1;
+    int ep = szm_ep(X.meta);
+    ep_legal = (ep >= 0) ? (__ballot(is_pawn && ((T >> ep) & 1)) != 0) : 0;
+    int n = 0;
+    for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
+        bool bit = T && sz_lane_plane_bit(T, is_pawn, lane, pl, I.white);
+        u64 w = __ballot(bit);
+        if (lane == 0) mask_lds[pl] = w;
+        n += __popcll(w);
+    }
+    n_legal = n;
+    checkers = I.checkers;
+}
+
+// earlier occurrences of X (key) within the reversible window: Board.is_repetition walk-back, lanes = plies
+__device__ int wave_count_reps(const BoardPtrs& bp, const int* path, int D, int root_ply, const SzPos& X) {
+    if (szm_irrev(X.meta)) return 0;
+    const int lane = lane_id();
+    int window = szm_half(X.meta);
+    if (window > SZ_RING - 1) window = SZ_RING - 1;
+    int reps = 0;
+    for (int base = 0; base < window; base += 64) {
+        int j = base + lane + 1;
+        bool in = j <= window;
+        const SzPos* a = in ? ancestor_ptr(bp, path, D, root_ply, j) : nullptr;
+        bool stop = in && (a == nullptr);
+        bool eq = false;
+        if (a) { u64 k = a->key, m = a->meta; eq = (k == X.key); stop = szm_irrev(m) != 0; }
+        u64 eqm = __ballot(eq), stm = __ballot(stop || !in);
+        if (stm) {
+            int sidx = __builtin_ctzll(stm);
+            u64 keep = (sidx >= 63) ? ~0ULL : ((2ULL << sidx) - 1);
+            reps += __popcll(eqm & keep);
+            break;
+        }
+        reps += __popcll(eqm);
+    }
+    return reps > 4 ? 4 : reps;
+}
+
+// stage the 8 history positions (leaf + 7 ancestors) as 8x8 u64 words in LDS
+__device__ void wave_load_history(const BoardPtrs& bp, const int* path, int D, int root_ply, const SzPos& X, u64* hist_lds) {
+    const int lane = lane_id();
+    const int t = lane >> 3, w = lane & 7;
+    u64 val = 0;
+    if (t == 0) {
+        val = w == 0 ? X.pc[0] : w == 1 ? X.pc[1] : w == 2 ? X.pc[2] : w == 3 ? X.pc[3] : w == 4 ? X.pc[4] : w == 5 ? X.pc[5] : w == 6 ? X.white : X.meta;
+    } else {
+        const SzPos* a = ancestor_ptr(bp, path, D, root_ply, t);
+        if (a) val = ((const u64*)a)[w];
+    }
+    hist_lds[lane] = val;
+}
+
+// chess_tensor.py:131-142 get_representation for the leaf whose history sits in hist_lds.
+// Every lane owns (plane, row): 8 cells = one 32-byte (f32) or 16-byte (bf16) store, fully coalesced.
+__device__ void wave_encode(const u64* hist_lds, const SzPos& X, void* out_board, int dtype, uint8_t* packed_out) {
+    const int lane = lane_id();
+    const int vw = szm_turn(X.meta);
+    const int r = lane & 7;
+    for (int i = 0; i < 15; i++) {
+        int c = i * 8 + (lane >> 3);
+        if (c >= SZ_NUM_PLANES) break;
+        u64 bb = (c < 112) ? sz_hist_plane(hist_lds + (c / 14) * 8, c % 14, vw) : sz_aux_plane(X, c - 112);
+        uint32_t bits = sz_row_bits(bb, r, vw);
+        if (packed_out) packed_out[c * 8 + r] = (uint8_t)bits;
+        if (!out_board) continue;
+        if (dtype == SZ_PLANES_F32) {
+            float4* dst = (float4*)out_board + (size_t)(c * 8 + r) * 2;
+            float4 a, b2;
+            a.x = (bits & 1) ? 1.f : 0.f; a.y = (bits & 2) ? 1.f : 0.f; a.z = (bits & 4) ? 1.f : 0.f; a.w = (bits & 8) ? 1.f : 0.f;
+            b2.x = (bits & 16) ? 1.f : 0.f; b2.y = (bits & 32) ? 1.f : 0.f; b2.z = (bits & 64) ? 1.f : 0.f; b2.w = (bits & 128) ? 1.f : 0.f;
+            dst[0] = a; dst[1] = b2;
+        } else {
+            uint4 o;                                       // bf16 1.0 = 0x3F80
+            o.x = ((bits & 1) ? 0x3F80u : 0u) | ((bits & 2) ? 0x3F800000u : 0u);
+            o.y = ((bits & 4) ? 0x3F80u : 0u) | ((bits & 8) ? 0x3F800000u : 0u);
+            o.z = ((bits & 16) ? 0x3F80u : 0u) | ((bits & 32) ? 0x3F800000u : 0u);
+            o.w = ((bits & 64) ? 0x3F80u : 0u) | ((bits & 128) ? 0x3F800000u : 0u);
+            ((uint4*)out_board)[c * 8 + r] = o;
+        }
+    }
+}
+
+// Node.backpropagate: one lane per level of the descent path (path[0] = root edge ... path[d] = leaf edge)
+__device__ __forceinline__ void wave_backprop(EdgeStat* es, const int* path, int d, double v) {
+    for (int j = lane_id(); j <= d; j += 64) {
+        EdgeStat* e = es + path[j];
+        double sv = ((d - j) & 1) ? -v : v;
+        e->W = e->W + sv;
+        e->N = e->N + 1;
+    }
+    __threadfence_block();
+}
+
+// make a new position from `parent` by action index and finish it (movegen, key, repetition, terminal).
+// D = tree depth of the new position; path[0..D-1] are the edges above it.
+__device__ SzPos wave_create_position(const BoardPtrs& bp, const SzPos& parent, int action, int chess960, const int* path, int D,
+                                      int root_ply, u64* mask_lds) {
+    int from, to, promo;
+    sz_action_decode(parent, action, from, to, promo);
+    SzPos X = sz_make_move(parent, from, to, promo, chess960);
+    int n_legal, ep_legal; u64 checkers;
+    wave_movegen(X, chess960, mask_lds, n_legal, ep_legal, checkers);
+    X.key = sz_hash_key(X, ep_legal);
+    int reps = wave_count_reps(bp, path, D, root_ply, X);
+    X.meta = sz_finish_meta(X, checkers, n_legal, ep_legal, reps);
+    return X;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: start games (ChessTensor.start_board)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_new_games(View v, const int* scharnagl, const uint8_t* active) {
+    extern __shared__ u64 lds64[];
+    const int b = blockIdx.x;
+    BoardPtrs bp = board_ptrs(v, b);
+    if (active && !active[b]) return;
+    int n = scharnagl ? scharnagl[b] : -1;
+    SzPos X = sz_startpos(n);
+    int n_legal, ep_legal; u64 checkers;
+    wave_movegen(X, v.chess960, lds64 + LDS_HIST_WORDS, n_legal, ep_legal, checkers);
+    X.key = sz_hash_key(X, ep_legal);
+    X.meta = sz_finish_meta(X, checkers, n_legal, ep_legal, 0);
+    if (lane_id() == 0) {
+        bp.ring[0] = X;
+        Ctl c; memset(&c, 0, sizeof c);
+        c.status = ST_ACTIVE;
+        *bp.ctl = c;
+    }
+}
+
+__global__ void k_set_active(View v, const uint8_t* active) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= v.B) return;
+    Ctl* c = v.ctl + b;
+    int st = c->status & ~(ST_ACTIVE);
+    if (active[b]) st |= ST_ACTIVE;
+    c->status = st;
+}
+
+// finish an uploaded game record (status only; the ring was copied by the host)
+__global__ void k_after_upload(View v, int b, int ply) {
+    Ctl* c = v.ctl + b;
+    Ctl z; memset(&z, 0, sizeof z);
+    z.status = ST_ACTIVE; z.game_ply = ply;
+    *c = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: search begin — create roots (mcts.py:43-46), root movegen + terminal test, encode root planes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
+    extern __shared__ u64 lds64[];
+    u64* hist = lds64; u64* mask = lds64 + LDS_HIST_WORDS; int* path = (int*)(lds64 + LDS_HIST_WORDS + LDS_MASK_WORDS);
+    const int b = blockIdx.x, lane = lane_id();
+    BoardPtrs bp = board_ptrs(v, b);
+    int status = uni(bp.ctl->status);
+    if (v.rec_active && lane == 0) v.rec_active[b] = 0;
+    if (!(status & ST_ACTIVE) || (status & (ST_GAMEOVER | ST_ERROR))) {
+        if (lane == 0) bp.ctl->status = status & ~(ST_PENDING | ST_DONE | ST_SEARCHING);
+        return;
+    }
+    const int root_ply = uni(bp.ctl->game_ply);
+    SzPos X = load_pos(bp.ring + (root_ply & (SZ_RING - 1)));
+    path[0] = 0;
+    if (lane == 0) {
+        bp.npos[0] = X;
+        EdgeStat s; s.W = 0.0; s.N = 1; s.P = 0.f;                 // root.visit_count = 1 (mcts.py:46)
+        bp.es[0] = s;
+        EdgeMeta m; m.first = -1; m.node = 0; m.n = 0; m.action = 0; m.term = (signed char)szm_term(X.meta);
+        m.tval = (signed char)(szm_loss(X.meta) ? -1 : 0); m.pad = 0;
+        bp.em[0] = m;
+        bp.gpath[0] = 0;
+    }
+    int st = (status & ST_ACTIVE) | ST_SEARCHING;
+    if (szm_term(X.meta) || v.S <= 0) {
+        // a terminal root: every simulation re-visits it (mcts.py:104-109); children stay empty
+        if (lane == 0) {
+            int S = v.S > 0 ? v.S : 0;
+            double tv = szm_loss(X.meta) ? -1.0 : 0.0;
+            bp.es[0].W = tv * (double)S; bp.es[0].N = 1 + S;
+            Ctl* c = bp.ctl; c->status = st | ST_DONE; c->n_nodes = 1; c->n_edges = 1; c->sims_done = S;
+            c->n_term += (unsigned long long)S; c->pend_node = -1; c->pend_depth = 0;
+        }
+        return;
+    }
+    int n_legal, ep_legal; u64 checkers;
+    wave_movegen(X, v.chess960, mask, n_legal, ep_legal, checkers);
+    __syncthreads();
+    for (int i = lane; i < SZ_MASK_WORDS; i += 64) bp.pmask[i] = mask[i];
+    wave_load_history(bp, path, 0, root_ply, X, hist);
+    __syncthreads();
+    size_t esz = v.planes_dtype == SZ_PLANES_F32 ? 4 : 2;
+    wave_encode(hist, X, planes ? (char*)planes + (size_t)b * SZ_NUM_PLANES * 64 * esz : nullptr, v.planes_dtype,
+                v.rec_planes ? v.rec_planes + (size_t)b * SZ_NUM_PLANES * 8 : nullptr);
+    if (lane == 0) {
+        Ctl* c = bp.ctl;
+        c->status = st | ST_PENDING; c->n_nodes = 1; c->n_edges = 1; c->sims_done = 0; c->pend_node = 0; c->pend_depth = 0;
+        if (v.rec_colour) v.rec_colour[b] = (uint8_t)szm_turn(X.meta);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: one lock-step iteration (expand + backprop of the evaluated leaf, then select / move /
+// terminal test / encode of the next one)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_step(View v, const float* __restrict__ policy, const float* __restrict__ value, void* planes) {
+    extern __shared__ u64 lds64[];
+    u64* hist = lds64; u64* mask = lds64 + LDS_HIST_WORDS; int* path = (int*)(lds64 + LDS_HIST_WORDS + LDS_MASK_WORDS);
+    const int b = blockIdx.x, lane = lane_id();
+    BoardPtrs bp = board_ptrs(v, b);
+    int status = uni(bp.ctl->status);
+    if (!(status & ST_SEARCHING) || (status & (ST_DONE | ST_ERROR))) return;
+    int n_nodes = uni(bp.ctl->n_nodes), n_edges = uni(bp.ctl->n_edges), sims = uni(bp.ctl->sims_done);
+    const int root_ply = uni(bp.ctl->game_ply);
+    unsigned long long n_expand = 0, n_term = 0, sum_depth = 0, sum_k = 0;
+    int err = 0;
+
+    if (status & ST_PENDING) {
+        // ---- mcts.py:77-109 for the leaf evaluated by the network -------------------------------
+        const int d = uni(bp.ctl->pend_depth), node = uni(bp.ctl->pend_node);
+        for (int j = lane; j <= d; j += 64) path[j] = bp.gpath[j];
+        for (int i = lane; i < SZ_MASK_WORDS; i += 64) mask[i] = bp.pmask[i];
+        __syncthreads();
+        const float* pol = policy + (size_t)b * SZ_NUM_ACTIONS;
+        // masked sum in the fixed order: per-lane partial over planes ascending, then xor butterfly
+        float acc = 0.0f;
+        for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
+            u64 w = mask[pl];
+            if (w == 0) continue;
+            if ((w >> lane) & 1) acc = acc + pol[pl * 64 + lane];
+        }
+        const float total = wave_sum_butterfly(acc);
+        const int first = n_edges;
+        int kept = 0;
+        const int leaf_edge = path[d];
+        for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
+            u64 w = mask[pl];
+            if (w == 0) continue;
+            bool mine = (w >> lane) & 1;
+            float p = 0.0f;
+            if (mine) p = pol[pl * 64 + lane] / total;                 // policy /= torch.sum(policy)
+            bool keep = mine && !(p == 0.0f);                          // policy.nonzero() (NaN stays)
+            u64 km = __ballot(keep);
+            if (keep) {
+                if (v.learning) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
+                int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
+                if (slot < v.e_cap) {
+                    EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
+                    bp.es[slot] = s;
+                    EdgeMeta m; m.first = -1; m.node = -1; m.n = 0; m.action = (unsigned short)(pl * 64 + lane); m.term = 0; m.tval = 0; m.pad = 0;
+                    bp.em[slot] = m;
+                }
+            }
+            kept += __popcll(km);
+        }
+        if (first + kept > v.e_cap) { err = SZ_ERR_CAPACITY; kept = 0; }
+        if (lane == 0) { bp.em[leaf_edge].first = first; bp.em[leaf_edge].n = (unsigned short)kept; }
+        n_edges += kept;
+        (void)node;
+        const double val = (double)value[b];                            // node.value = value.item()
+        wave_backprop(bp.es, path, d, val);
+        sims++; n_expand++; sum_depth += d; sum_k += kept;
+        status &= ~ST_PENDING;
+    }
+
+    // ---- next simulation(s): mcts.py:49-64 ------------------------------------------------------
+    while (sims < v.S && !err) {
+        int d = 0, cur = 0;
+        path[0] = 0;
+        EdgeMeta m = bp.em[0];
+        int parentN = bp.es[0].N;
+        m.first = uni(m.first); int mn = uni((int)m.n); parentN = uni(parentN);
+        while (mn > 0) {                                                // Node.select
+            const float sq = (float)sqrt((double)parentN);
+            float best = 0.f; int bi = 0x7fffffff;
+            for (int c = lane; c < mn; c += 64) {
+                EdgeStat s = bp.es[m.first + c];
+                float u = ucb_value(s.N, s.W, s.P, sq, v.c_puct);
+                if (bi == 0x7fffffff || u > best) { best = u; bi = c; }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                float ob = __shfl_xor(best, off); int oi = __shfl_xor(bi, off);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+            }
+            bi = uni(bi);
+            cur = m.first + bi;
+            d++;
+            if (d >= v.p_cap) { err = SZ_ERR_CAPACITY; break; }
+            path[d] = cur;
+            m = bp.em[cur];
+            parentN = uni(bp.es[cur].N);
+            m.first = uni(m.first); mn = uni((int)m.n);
+        }
+        if (err) break;
+        int node = uni(m.node);
+        if (node >= 0) {
+            // visited leaf without children: a terminal position (mcts.py:104-109)
+            double tv = (double)(int)m.tval;
+            wave_backprop(bp.es, path, d, tv);
+            sims++; n_term++; sum_depth += d;
+            continue;
+        }
+        // first visit: node.game = deepcopy(parent.game); move_piece(action)   (mcts.py:57-59)
+        if (n_nodes >= v.n_cap) { err = SZ_ERR_CAPACITY; break; }
+        const int parent_node = uni(bp.em[path[d - 1]].node);
+        SzPos P = load_pos(bp.npos + parent_node);
+        SzPos X = wave_create_position(bp, P, (int)uni((int)m.action), v.chess960, path, d, root_ply, mask);
+        const int nid = n_nodes++;
+        const int is_term = szm_term(X.meta);
+        if (lane == 0) {
+            bp.npos[nid] = X;
+            EdgeMeta* em = bp.em + cur;
+            em->node = nid; em->term = (signed char)is_term; em->tval = (signed char)(szm_loss(X.meta) ? -1 : 0);
+        }
+        __threadfence_block();
+        if (is_term) {                                                  // get_value_and_terminated -> (0|-1, True)
+            double tv = szm_loss(X.meta) ? -1.0 : 0.0;
+            wave_backprop(bp.es, path, d, tv);
+            sims++; n_term++; sum_depth += d;
+            continue;
+        }
+        // non-terminal leaf: hand it to the network
+        __syncthreads();
+        for (int i = lane; i < SZ_MASK_WORDS; i += 64) bp.pmask[i] = mask[i];
+        for (int j = lane; j <= d; j += 64) bp.gpath[j] = path[j];
+        wave_load_history(bp, path, d, root_ply, X, hist);
+        __syncthreads();
+        size_t esz = v.planes_dtype == SZ_PLANES_F32 ? 4 : 2;
+        wave_encode(hist, X, (char*)planes + (size_t)b * SZ_NUM_PLANES * 64 * esz, v.planes_dtype, nullptr);
+        status |= ST_PENDING;
+        if (lane == 0) { bp.ctl->pend_node = nid; bp.ctl->pend_depth = d; }
+        break;
+    }
+    if (sims >= v.S && !(status & ST_PENDING)) status |= ST_DONE;
+    if (err) status |= ST_ERROR;
+    if (lane == 0) {
+        Ctl* c = bp.ctl;
+        c->status = status; c->n_nodes = n_nodes; c->n_edges = n_edges; c->sims_done = sims;
+        c->n_expand += n_expand; c->n_term += n_term; c->sum_depth += sum_depth; c->sum_k += sum_k;
+        if (n_edges > c->max_edges) c->max_edges = n_edges;
+        if (err && !c->err) c->err = err;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: root readout (mcts.py:113-122)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_root_children(View v, int* action, int* visits, int* n_child, float* prior, double* wsum) {
+    const int b = blockIdx.x, lane = lane_id();
+    BoardPtrs bp = board_ptrs(v, b);
+    int status = bp.ctl->status;
+    int n = 0, first = 0;
+    if (status & ST_SEARCHING) { EdgeMeta m = bp.em[0]; n = m.n; first = m.first; }
+    if (lane == 0) n_child[b] = n;
+    for (int c = lane; c < SZ_MAX_CHILDREN; c += 64) {
+        size_t o = (size_t)b * SZ_MAX_CHILDREN + c;
+        if (c < n) {
+            EdgeStat s = bp.es[first + c];
+            action[o] = bp.em[first + c].action; visits[o] = s.N;
+            if (prior) prior[o] = s.P;
+            if (wsum) wsum[o] = s.W;
+        } else {
+            action[o] = -1; visits[o] = 0;
+            if (prior) prior[o] = 0.f;
+            if (wsum) wsum[o] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel: sample + play (sim.py:63-76) and game-over test (sim.py:46, 86-97)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_play(View v, const double* uniforms) {
+    extern __shared__ u64 lds64[];
+    u64* mask = lds64 + LDS_HIST_WORDS; int* path = (int*)(lds64 + LDS_HIST_WORDS + LDS_MASK_WORDS);
+    int* vis_lds = path + 8;
+    const int b = blockIdx.x, lane = lane_id();
+    BoardPtrs bp = board_ptrs(v, b);
+    int status = uni(bp.ctl->status);
+    if (!(status & ST_SEARCHING) || !(status & ST_DONE) || (status & (ST_ERROR | ST_GAMEOVER))) return;
+    EdgeMeta rm = bp.em[0];
+    const int n = uni((int)rm.n), first = uni(rm.first);
+    const int root_ply = uni(bp.ctl->game_ply);
+    int total = 0;
+    for (int c = lane; c < SZ_MAX_CHILDREN; c += 64) {
+        int nv = 0, act = -1;
+        if (c < n) { nv = bp.es[first + c].N; act = bp.em[first + c].action; }
+        vis_lds[c] = nv;
+        total += nv;
+        if (v.rec_action) { v.rec_action[(size_t)b * SZ_MAX_CHILDREN + c] = act; v.rec_visits[(size_t)b * SZ_MAX_CHILDREN + c] = nv; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+    __syncthreads();
+    if (n == 0 || total == 0) {                                          // ZeroDivisionError in the reference (mcts.py:118-120)
+        if (lane == 0) { bp.ctl->status = status | ST_ERROR; if (!bp.ctl->err) bp.ctl->err = SZ_ERR_ZERO_VISITS; }
+        return;
+    }
+    // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, 'right')   (sequential f64, like numpy)
+    int chosen = 0;
+    if (lane == 0) {
+        const double u = uniforms[b];
+        double acc = 0.0;
+        for (int c = 0; c < n; c++) acc += (double)vis_lds[c] / (double)total;
+        const double last = acc;
+        acc = 0.0;
+        int idx = 0;
+        for (int c = 0; c < n; c++) { acc += (double)vis_lds[c] / (double)total; if (acc / last <= u) idx = c + 1; }
+        if (idx >= n) idx = n - 1;
+        chosen = idx;
+    }
+    chosen = uni(chosen);
+    const int action = uni((int)bp.em[first + chosen].action);
+    SzPos R = load_pos(bp.npos);
+    path[0] = 0;
+    SzPos X = wave_create_position(bp, R, action, v.chess960, path, 1, root_ply, mask);
+    const int over = szm_term(X.meta);
+    int result = 0;
+    if (over && szm_loss(X.meta)) result = szm_turn(X.meta) ? -1 : 1;      // side to move is mated
+    if (lane == 0) {
+        bp.ring[(root_ply + 1) & (SZ_RING - 1)] = X;
+        Ctl* c = bp.ctl;
+        c->game_ply = root_ply + 1;
+        c->status = (status & ST_ACTIVE) | (over ? ST_GAMEOVER : 0);
+        c->game_result = result;
+        if (v.rec_nchild) { v.rec_nchild[b] = n; v.rec_chosen[b] = action; v.rec_over[b] = (uint8_t)over; v.rec_result[b] = (int8_t)result; v.rec_active[b] = 1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: the C ABI
+// ------------------------------------------------------------------------------------------------
+struct sz_engine {
+    sz_config cfg;
+    View v;
+    size_t lds_bytes;
+    std::vector<void*> allocs;
+    int* d_scharnagl; uint8_t* d_active;
+};
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
+
+template <typename T> static int dalloc(sz_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, count * sizeof(T));
+    if (err != hipSuccess) { fprintf(stderr, "[sigmazero] hipMalloc(%zu bytes) failed: %s\n", count * sizeof(T), hipGetErrorString(err)); return SZ_ERR_HIP; }
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return SZ_OK;
+}
+
+extern "C" {
+
+const char* sz_error_string(int code) {
+    switch (code) {
+        case SZ_OK: return "ok";
+        case SZ_ERR_INVALID: return "invalid argument or illegal move";
+        case SZ_ERR_HIP: return "HIP runtime error";
+        case SZ_ERR_CAPACITY: return "node/edge capacity exhausted on a board";
+        case SZ_ERR_NO_DEVICE: return "no HIP device: the engine has no CPU fallback";
+        case SZ_ERR_STATE: return "call sequence violated";
+        case SZ_ERR_ZERO_VISITS: return "root children have no visits (num_searches == 1 divides by zero in the reference)";
+        default: return "unknown error";
+    }
+}
+
+int sz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sz_create(const sz_config* cfg, sz_engine** out) {
+    if (!cfg || !out || cfg->n_boards <= 0 || cfg->num_searches < 0) return SZ_ERR_INVALID;
+    if (sz_device_count() <= 0) return SZ_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(cfg->device));
+    sz_engine* e = new sz_engine();
+    e->cfg = *cfg;
+    View& v = e->v;
+    memset(&v, 0, sizeof v);
+    v.B = cfg->n_boards; v.S = cfg->num_searches;
+    v.n_cap = cfg->num_searches + 2;
+    v.e_cap = cfg->edges_per_board > 0 ? cfg->edges_per_board : cfg->num_searches * 64 + 256;
+    if (v.e_cap < SZ_MAX_CHILDREN + 2) v.e_cap = SZ_MAX_CHILDREN + 2;
+    v.p_cap = cfg->num_searches + 2;
+    v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
+    v.c_puct = cfg->c_puct; v.noise = cfg->noise_value;
+    e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4;
+    if (e->lds_bytes > 64 * 1024) { delete e; return SZ_ERR_INVALID; }
+    const size_t B = v.B;
+    int rc = SZ_OK;
+    if ((rc = dalloc(e, &v.npos, B * v.n_cap)) || (rc = dalloc(e, &v.ring, B * SZ_RING)) || (rc = dalloc(e, &v.es, B * v.e_cap)) ||
+        (rc = dalloc(e, &v.em, B * v.e_cap)) || (rc = dalloc(e, &v.gpath, B * v.p_cap)) || (rc = dalloc(e, &v.pmask, B * PMASK_STRIDE)) ||
+        (rc = dalloc(e, &v.ctl, B)) || (rc = dalloc(e, &v.rec_planes, B * SZ_NUM_PLANES * 8)) ||
+        (rc = dalloc(e, &v.rec_action, B * SZ_MAX_CHILDREN)) || (rc = dalloc(e, &v.rec_visits, B * SZ_MAX_CHILDREN)) ||
+        (rc = dalloc(e, &v.rec_nchild, B)) || (rc = dalloc(e, &v.rec_colour, B)) || (rc = dalloc(e, &v.rec_chosen, B)) ||
+        (rc = dalloc(e, &v.rec_over, B)) || (rc = dalloc(e, &v.rec_result, B)) || (rc = dalloc(e, &v.rec_active, B)) ||
+        (rc = dalloc(e, &e->d_scharnagl, B)) || (rc = dalloc(e, &e->d_active, B))) {
+        sz_destroy(e);
+        return rc;
+    }
+    HIPCHK(hipMemset(v.ctl, 0, B * sizeof(Ctl)));
+    HIPCHK(hipMemset(v.ring, 0, B * SZ_RING * sizeof(SzPos)));
+    HIPCHK(hipMemset(v.rec_active, 0, B));
+    HIPCHK(hipDeviceSynchronize());
+    *out = e;
+    return SZ_OK;
+}
+
+int sz_destroy(sz_engine* e) {
+    if (!e) return SZ_OK;
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+    return SZ_OK;
+}
+
+int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, void* stream) {
+    if (!e) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = e->v.B;
+    std::vector<int> sch(B, -1);
+    if (scharnagl) for (size_t i = 0; i < B; i++) sch[i] = scharnagl[i];
+    HIPCHK(hipMemcpyAsync(e->d_scharnagl, sch.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    if (active) HIPCHK(hipMemcpyAsync(e->d_active, active, B, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                    // host staging buffers go out of scope
+    hipLaunchKernelGGL(k_new_games, dim3(e->v.B), dim3(64), e->lds_bytes, s, e->v, e->d_scharnagl, active ? e->d_active : nullptr);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_set_active(sz_engine* e, const uint8_t* active, void* stream) {
+    if (!e || !active) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->d_active, active, e->v.B, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_set_active, dim3((e->v.B + 255) / 256), dim3(256), 0, s, e->v, e->d_active);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_upload_game(sz_engine* e, int32_t board, const void* ring, int32_t ply, void* stream) {
+    if (!e || !ring || board < 0 || board >= e->v.B || ply < 0) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->v.ring + (size_t)board * SZ_RING, ring, SZ_RING * sizeof(SzPos), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_after_upload, dim3(1), dim3(1), 0, s, e->v, board, ply);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_search_begin(sz_engine* e, void* planes_dev, void* stream) {
+    if (!e) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_search_begin, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, planes_dev);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_search_step(sz_engine* e, const float* policy_dev, const float* value_dev, void* planes_dev, void* stream) {
+    if (!e || !policy_dev || !value_dev || !planes_dev) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_search_step, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, policy_dev, value_dev, planes_dev);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_get_stats(sz_engine* e, sz_stats* out, void* stream) {
+    if (!e || !out) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<Ctl> h(e->v.B);
+    HIPCHK(hipMemcpyAsync(h.data(), e->v.ctl, h.size() * sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    for (const Ctl& c : h) {
+        out->expansions += c.n_expand; out->terminal_hits += c.n_term; out->sum_depth += c.sum_depth; out->sum_children += c.sum_k;
+        if ((uint64_t)c.max_edges > out->max_edges_used) out->max_edges_used = c.max_edges;
+        if (c.status & ST_PENDING) out->boards_pending++;
+        if (c.status & ST_DONE) out->boards_done++;
+        if (c.status & ST_ERROR) { out->boards_error++; if (!out->first_error) out->first_error = c.err; }
+    }
+    out->simulations = out->expansions + out->terminal_hits;
+    return SZ_OK;
+}
+
+int sz_root_children(sz_engine* e, int32_t* action_dev, int32_t* visits_dev, int32_t* n_child_dev, float* prior_dev, double* value_sum_dev, void* stream) {
+    if (!e || !action_dev || !visits_dev || !n_child_dev) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_root_children, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, action_dev, visits_dev, n_child_dev, prior_dev, value_sum_dev);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_play(sz_engine* e, const double* uniforms_dev, void* stream) {
+    if (!e || !uniforms_dev) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_play, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, uniforms_dev);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t* visits, int32_t* n_child, uint8_t* colour, int32_t* chosen,
+                 uint8_t* game_over, int8_t* result, uint8_t* active, void* stream) {
+    if (!e) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = e->v.B;
+    const View& v = e->v;
+    if (packed_planes) HIPCHK(hipMemcpyAsync(packed_planes, v.rec_planes, B * SZ_NUM_PLANES * 8, hipMemcpyDeviceToHost, s));
+    if (action) HIPCHK(hipMemcpyAsync(action, v.rec_action, B * SZ_MAX_CHILDREN * 4, hipMemcpyDeviceToHost, s));
+    if (visits) HIPCHK(hipMemcpyAsync(visits, v.rec_visits, B * SZ_MAX_CHILDREN * 4, hipMemcpyDeviceToHost, s));
+    if (n_child) HIPCHK(hipMemcpyAsync(n_child, v.rec_nchild, B * 4, hipMemcpyDeviceToHost, s));
+    if (colour) HIPCHK(hipMemcpyAsync(colour, v.rec_colour, B, hipMemcpyDeviceToHost, s));
+    if (chosen) HIPCHK(hipMemcpyAsync(chosen, v.rec_chosen, B * 4, hipMemcpyDeviceToHost, s));
+    if (game_over) HIPCHK(hipMemcpyAsync(game_over, v.rec_over, B, hipMemcpyDeviceToHost, s));
+    if (result) HIPCHK(hipMemcpyAsync(result, v.rec_result, B, hipMemcpyDeviceToHost, s));
+    if (active) HIPCHK(hipMemcpyAsync(active, v.rec_active, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SZ_OK;
+}
+
+int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges, int32_t* status, void* stream) {
+    if (!e) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = e->v.B;
+    std::vector<Ctl> h(B);
+    std::vector<u64> pm(mask ? B * PMASK_STRIDE : 0);
+    HIPCHK(hipMemcpyAsync(h.data(), e->v.ctl, B * sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    if (mask) HIPCHK(hipMemcpyAsync(pm.data(), e->v.pmask, pm.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; b++) {
+        if (depth) depth[b] = h[b].pend_depth;
+        if (n_nodes) n_nodes[b] = h[b].n_nodes;
+        if (n_edges) n_edges[b] = h[b].n_edges;
+        if (status) status[b] = h[b].status;
+        if (mask) memcpy(mask + b * SZ_MASK_WORDS, pm.data() + b * PMASK_STRIDE, SZ_MASK_WORDS * 8);
+    }
+    return SZ_OK;
+}
+
+int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, void* stream) {
+    if (!e || board < 0 || board >= e->v.B || !pos_out) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    Ctl c;
+    HIPCHK(hipMemcpyAsync(&c, e->v.ctl + board, sizeof c, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpyAsync(pos_out, e->v.ring + (size_t)board * SZ_RING + (c.game_ply & (SZ_RING - 1)), sizeof(SzPos), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ply) *ply = c.game_ply;
+    return SZ_OK;
+}
+
+}  // extern "C"

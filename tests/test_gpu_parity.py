@@ -1,0 +1,247 @@
+"""GPU parity: the HIP engine (through the C ABI) against the oracle, on the same seeded inputs.
+Integer/index results must be bit-exact; priors and value sums are compared bitwise too because both
+sides are fed the identical (policy, value) numbers."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import sigma_zero_amd as sz
+from sigma_zero_amd import _native as N
+from sigma_zero_amd.selfplay import SelfPlayEngine, unpack_planes, NOISE_REFERENCE
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FENS = [
+    "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1",
+    "8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1",
+    "r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1",
+    "rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8",
+    "7k/5Q2/5K2/8/8/8/8/8 w - - 0 1",                 # mates and stalemates one ply away: terminal leaves everywhere
+    "8/8/8/8/8/5k2/4p3/4K3 b - - 0 1",
+    "6k1/5ppp/8/8/8/8/5PPP/R5K1 w - - 0 1",           # back-rank mate in one
+    "8/P7/8/8/8/8/7k/K7 w - - 0 1",                   # promotions (queen + under-promotions)
+    "4k3/8/8/8/8/8/8/4K2R w K - 0 1",                 # castling with few pieces
+    "8/8/4k3/8/8/3KR3/8/8 w - - 140 100",             # 75-move rule inside the tree
+]
+
+
+class Mirror:
+    """One board: product host game (for upload) + oracle game + oracle search."""
+
+    def __init__(self, c960=False, scharnagl=518, fen=None, pre_moves=0, rng=None):
+        self.ct = sz.ChessTensor(chess960=c960, scharnagl=scharnagl, fen=fen)
+        self.oct = O.ChessTensor.from_fen(fen, chess960=c960) if fen else O.ChessTensor(chess960=c960, scharnagl=scharnagl)
+        for _ in range(pre_moves):
+            if self.ct.board.is_game_over():
+                break
+            idx, moves = self.oct.legal_action_indices()
+            k = rng.randrange(len(idx))
+            self.ct.push_action(idx[k])
+            self.oct.move_piece(moves[k])
+        self.search = None
+
+
+def make_boards(n, seed, c960=False):
+    rng = random.Random(seed)
+    boards = []
+    for i in range(n):
+        if i < len(FENS) and not c960:
+            boards.append(Mirror(fen=FENS[i]))
+        else:
+            boards.append(Mirror(c960=c960, scharnagl=rng.randrange(960), pre_moves=rng.randrange(0, 40), rng=rng))
+    return boards
+
+
+def lockstep_search(boards, S, learning, evaluator, c960=False, dtype=torch.float32):
+    B = len(boards)
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=c960, learning=learning, planes_dtype=dtype)
+    for b, m in enumerate(boards):
+        eng.upload_game(b, m.ct)
+        m.search = O.Search.on_chess(m.oct, c=2.0, num_searches=S, learning=learning, noise_value=NOISE_REFERENCE)
+    eng.begin()
+    n_evals = 0
+    for step in range(S + 1):
+        torch.cuda.synchronize()
+        mask, depth, n_nodes, n_edges, status = eng.debug_pending()
+        planes = eng.planes.float().cpu().numpy()
+        pending = [(status[b] & 2) != 0 for b in range(B)]
+        o_pending = [m.search.advance() for m in boards]
+        assert pending == o_pending, "step %d: pending sets differ" % step
+        if not any(pending):
+            break
+        for b, m in enumerate(boards):
+            if not pending[b]:
+                continue
+            assert np.array_equal(planes[b].astype(np.uint8), m.search.leaf_planes()), "step %d board %d planes" % (step, b)
+            legal = m.search.leaf_actions()
+            mine = [p * 64 + v for p in range(73) for v in range(64) if (int(mask[b, p]) >> v) & 1]
+            assert mine == legal, "step %d board %d legal mask" % (step, b)
+            assert depth[b] == len(m.search.trace()), "step %d board %d depth" % (step, b)
+        policy, value = evaluator(eng.planes, step)
+        pol_h, val_h = policy.cpu().numpy(), value.cpu().numpy()
+        for b, m in enumerate(boards):
+            if pending[b]:
+                m.search.feed(pol_h[b], val_h[b])
+                n_evals += 1
+        eng.step(policy, value)
+    st = eng.check_errors()
+    action, visits, n_child, prior, wsum = eng.root_children()
+    for b, m in enumerate(boards):
+        idx, vis, _ = m.search.root_children()
+        k = int(n_child[b])
+        assert k == len(idx), "board %d child count" % b
+        assert action[b, :k].tolist() == idx, "board %d child order" % b
+        assert visits[b, :k].tolist() == vis, "board %d visits" % b
+        pr, ws = m.search.root_stats()
+        assert np.array_equal(prior[b, :k].view(np.uint32), pr.view(np.uint32)), "board %d priors" % b
+        assert np.array_equal(wsum[b, :k], ws), "board %d value sums" % b
+    exp = sum(m.search.counters()[0] for m in boards)
+    term = sum(m.search.counters()[1] for m in boards)
+    assert st["expansions"] == exp == n_evals and st["terminal_hits"] == term
+    eng.close()
+    return st
+
+
+def random_evaluator(seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+
+    def ev(planes, step):
+        B = planes.shape[0]
+        logits = torch.randn(B, N.SZ_ACTIONS, generator=g, device="cuda") * 2.0
+        return torch.softmax(logits, 1).contiguous(), (torch.rand(B, generator=g, device="cuda") * 2 - 1).contiguous()
+    return ev
+
+
+@pytest.mark.parametrize("learning", [False, True])
+def test_lockstep_search_matches_oracle(learning):
+    boards = make_boards(24, seed=7)
+    st = lockstep_search(boards, S=64, learning=learning, evaluator=random_evaluator(11 + learning))
+    assert st["terminal_hits"] > 0 and st["expansions"] > 0
+
+
+def test_lockstep_search_chess960_deeper():
+    boards = make_boards(12, seed=21, c960=True)
+    lockstep_search(boards, S=200, learning=True, evaluator=random_evaluator(5), c960=True)
+
+
+def test_peaked_policies_drop_zero_priors_and_go_deep():
+    # very peaked policies: some legal moves get probability exactly 0 (dropped children), trees go deep
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def ev(planes, step):
+        B = planes.shape[0]
+        logits = torch.randn(B, N.SZ_ACTIONS, generator=g, device="cuda") * 60.0
+        return torch.softmax(logits, 1).contiguous(), (torch.rand(B, generator=g, device="cuda") * 2 - 1).contiguous()
+    boards = make_boards(16, seed=9)
+    lockstep_search(boards, S=120, learning=False, evaluator=ev)
+
+
+def test_real_network_fp32_end_to_end():
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+
+    def ev(planes, step):
+        with torch.no_grad():
+            p, v = net(planes, inference=True)
+        return p.float().contiguous(), v.float().reshape(-1).contiguous()
+    boards = make_boards(8, seed=33)
+    lockstep_search(boards, S=24, learning=True, evaluator=ev)
+
+
+def test_bf16_planes_are_the_same_bits():
+    boards = make_boards(12, seed=4)
+    lockstep_search(boards, S=16, learning=False, evaluator=random_evaluator(2), dtype=torch.bfloat16)
+
+
+def test_selfplay_games_match_oracle():
+    """Several plies of self-play: sampling (np.random.choice semantics), move application, game-over test,
+    training records — against oracle search + oracle sampler on the same uniforms."""
+    S, B, PLIES = 12, 12, 40
+    rng = random.Random(5)
+    sch = [rng.randrange(960) for _ in range(B)]
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=True, learning=True)
+    eng.new_games(sch)
+    octs = [O.ChessTensor(chess960=True, scharnagl=n) for n in sch]
+    alive = [True] * B
+    ev = random_evaluator(77)
+    urng = np.random.RandomState(1)
+    for ply in range(PLIES):
+        searches = [O.Search.on_chess(o, c=2.0, num_searches=S, learning=True, noise_value=NOISE_REFERENCE) if alive[b] else None
+                    for b, o in enumerate(octs)]
+        eng.begin()
+        for step in range(S):
+            policy, value = ev(eng.planes, step)
+            pol_h, val_h = policy.cpu().numpy(), value.cpu().numpy()
+            for b, s in enumerate(searches):
+                if s is not None and s.advance():
+                    s.feed(pol_h[b], val_h[b])
+            eng.step(policy, value)
+        u = urng.random_sample(B)
+        eng.play(u)
+        rec = eng.fetch_ply()
+        eng.check_errors()
+        for b, s in enumerate(searches):
+            if s is None:
+                assert not rec["active"][b]
+                continue
+            assert not s.advance()
+            idx, vis, moves = s.root_children()
+            k = int(rec["n_child"][b])
+            assert rec["active"][b] and k == len(idx)
+            assert rec["action"][b, :k].tolist() == idx and rec["visits"][b, :k].tolist() == vis
+            assert bool(rec["colour"][b]) == bool(octs[b].turn)
+            assert np.array_equal(unpack_planes(rec["packed"][b]).astype(np.uint8), octs[b].get_representation())
+            choice = O.sample_move(vis, u[b])
+            assert int(rec["chosen"][b]) == idx[choice], "ply %d board %d sampled move" % (ply, b)
+            octs[b].move_piece(moves[choice])
+            v, t = octs[b].get_value_and_terminated()
+            assert bool(rec["game_over"][b]) == t
+            if t:
+                o, w = octs[b].board.outcome()
+                assert int(rec["result"][b]) == (0 if w < 0 else (1 if w == 1 else -1))
+                alive[b] = False
+            pos, gply = eng.debug_position(b)
+            assert [int(x) for x in pos[:7]] == octs[b].board.bitboards()[:7] and gply == octs[b].board.ply
+        if not any(alive):
+            break
+    eng.close()
+
+
+def test_mcts0_api_single_position():
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    game = sz.ChessTensor()
+    for u in ("e2e4", "e7e5", "g1f3"):
+        game.move_piece(sz.Move.from_uci(u))
+    args = {"C": 2, "num_searches": 40}
+    probs = sz.MCTS0(game=game, args=args, model=net).search(game.board, verbose=False, learning=False)
+    assert abs(sum(probs.values()) - 1.0) < 1e-12 and len(probs) == len(game.get_moves())
+    keys = [sz.chess_tensor.action_index(m, game.board.turn) for m in probs]
+    assert keys == sorted(keys)
+    # same search through the oracle with the same fp32 network on the same device
+    oct_ = O.ChessTensor()
+    for u in ("e2e4", "e7e5", "g1f3"):
+        oct_.move_piece(O.Move.from_uci(u))
+
+    def ev(planes):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(planes.astype(np.float32)).cuda().unsqueeze(0), inference=True)
+        return p[0].float().cpu().numpy(), float(v.reshape(-1)[0])
+    s = O.search_with_evaluator(oct_, ev, c=2.0, num_searches=40, learning=False)
+    ref = s.action_probs()
+    assert keys == list(ref.keys())
+    # batch-1 evaluations on both sides: visit fractions agree to 1e-4 (north_star tolerance), indices exactly
+    assert np.allclose(list(probs.values()), list(ref.values()), atol=1e-4)
+    with pytest.raises(ZeroDivisionError):
+        sz.MCTS0(game=game, args={"C": 2, "num_searches": 1}, model=net).search(game.board, verbose=False)
+
+
+def test_sqrt_visits_rounding_matches_host():
+    # f32(sqrt_f64(N)) on the device equals the host's for every parent visit count a search can reach
+    n = torch.arange(1, 1 << 20, device="cuda", dtype=torch.float64)
+    dev = torch.sqrt(n).float().cpu().numpy()
+    host = np.sqrt(np.arange(1, 1 << 20, dtype=np.float64)).astype(np.float32)
+    assert np.array_equal(dev, host)

@@ -1,0 +1,134 @@
+"""Product rules code (csrc/sz_chess.h through the szh_* host mirror; the same functions the HIP kernels run)
+against the independent oracle (oracle/oc_chess.c, oc_tensor.c) and public perft tables.  CPU only."""
+import random
+
+import numpy as np
+import pytest
+
+import sigma_zero_amd as sz
+from sigma_zero_amd import _native as N
+from oracle import oracle as O
+
+PERFT = [
+    ("startpos", None, False, [20, 400, 8902, 197281]),
+    ("kiwipete", "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", False, [48, 2039, 97862]),
+    ("pos3", "8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1", False, [14, 191, 2812, 43238, 674624]),
+    ("pos4", "r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1", False, [6, 264, 9467, 422333]),
+    ("pos5", "rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8", False, [44, 1486, 62379]),
+    ("pos6", "r4rk1/1pp1qppp/p1np1n2/2b1p1B1/2B1P1b1/P1NP1N2/1PP1QPPP/R4RK1 w - - 0 10", False, [46, 2079, 89890]),
+    ("c960", "bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9", True, [21, 528, 12189, 326672]),
+]
+
+
+@pytest.mark.parametrize("name,fen,c960,want", PERFT, ids=[p[0] for p in PERFT])
+def test_perft(name, fen, c960, want):
+    ct = sz.ChessTensor(chess960=c960, fen=fen) if fen else sz.ChessTensor()
+    assert [ct.perft(d + 1) for d in range(len(want))] == want
+
+
+def test_scharnagl_matches_oracle():
+    for n in list(range(0, 960, 7)) + [518, 959]:
+        ct = sz.ChessTensor(chess960=True, scharnagl=n)
+        ob = O.Board.from_chess960_pos(n)
+        bb = ct.board.bitboards()
+        assert bb[:6] == ob.bitboards()[:6] and bb[6] == ob.bitboards()[6]
+        assert bb[9] == ob.castling_rights
+
+
+def _compare_state(ct, oct_, tag):
+    ob = oct_.board
+    # legal move set in action-index order
+    mine = ct.legal_action_indices()
+    theirs, their_moves = oct_.legal_action_indices()
+    assert mine == theirs, tag
+    assert [m.uci() for m in ct.get_moves()] == [m.uci() for m in their_moves], tag
+    # encoder
+    assert np.array_equal(ct.get_representation().numpy().astype(np.uint8), oct_.get_representation()), tag
+    # terminal
+    v, t = ct.get_value_and_terminated()
+    ov, ot = oct_.get_value_and_terminated()
+    assert (v, t) == (ov, ot), tag
+    st = ct.board._st()
+    assert st[0] == ob.turn and st[2] == min(ob.halfmove_clock, 255) and st[3] == ob.ep_square, tag
+    assert st[10] == int(ob.has_legal_en_passant()), tag
+    assert st[7] >= 1 if ob.is_repetition(2) else st[7] == 0, tag
+    assert (st[7] >= 2) == ob.is_repetition(3), tag
+    if t:
+        assert st[9] == ob.outcome()[0], tag
+    return t
+
+
+@pytest.mark.parametrize("c960", [False, True])
+def test_random_games_match_oracle(c960):
+    rng = random.Random(2024 + c960)
+    n_plies = 0
+    for game in range(12):
+        n = rng.randrange(960)
+        ct = sz.ChessTensor(chess960=c960, scharnagl=n)
+        oct_ = O.ChessTensor(chess960=c960, scharnagl=n)
+        for ply in range(400):
+            if _compare_state(ct, oct_, "game %d ply %d" % (game, ply)):
+                break
+            idx, moves = oct_.legal_action_indices()
+            k = rng.randrange(len(idx))
+            # bias towards shuffling so that repetitions and the no-progress clock get exercised
+            if rng.random() < 0.35:
+                quiet = [i for i, m in enumerate(moves) if ct.board.bitboards()[0] >> m.from_square & 1 == 0]
+                if quiet:
+                    k = rng.choice(quiet)
+            ct.push_action(idx[k])
+            oct_.move_piece(moves[k])
+            n_plies += 1
+    assert n_plies > 1500
+
+
+def test_fivefold_and_seventyfive():
+    ct = sz.ChessTensor()
+    for rep in range(4):
+        for u in ("g1f3", "g8f6", "f3g1", "f6g8"):
+            assert not ct.board.is_game_over()
+            ct.move_piece(sz.Move.from_uci(u))
+    assert ct.board.is_game_over() and ct.board.result() == "1/2-1/2" and ct.board.outcome().termination == 5
+    ct = sz.ChessTensor(fen="8/8/4k3/8/8/3KR3/8/8 w - - 149 100")
+    assert not ct.board.is_game_over()
+    ct.move_piece(sz.Move.from_uci("e3e4"))
+    assert ct.board.is_game_over() and ct.board.outcome().termination == 4
+
+
+def test_invalid_move_raises():
+    ct = sz.ChessTensor()
+    with pytest.raises(ValueError, match="Invalid move"):
+        ct.move_piece(sz.Move.from_uci("e2e5"))
+    with pytest.raises(ValueError, match="Invalid move"):
+        ct.move_piece(sz.Move.from_uci("e1g1"))
+
+
+def test_checkmate_value():
+    ct = sz.ChessTensor()
+    for u in ("f2f3", "e7e5", "g2g4", "d8h4"):
+        ct.move_piece(sz.Move.from_uci(u))
+    assert ct.get_value_and_terminated() == (-1, True)
+    assert ct.board.result() == "0-1"
+
+
+def test_codec_matches_oracle_tables(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "codec_tables.npz"))
+    enc, dec = z["encode"], z["decode"]
+    for color, f, t, p, idx in enc:
+        assert sz.chess_tensor.action_index(sz.Move(int(f), int(t), int(p) or None), bool(color)) == int(idx)
+    for color, idx, f, t, p, use_qp in dec:
+        qp = {sz.Move(int(f), int(t), 5).uci(): True} if use_qp else {}
+        m = sz.chess_tensor.index_to_move(int(idx), bool(color), qp)
+        assert (m.from_square, m.to_square, m.promotion or 0) == (int(f), int(t), int(p))
+
+
+def test_library_exports_every_declared_symbol():
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "sigmazero.h")).read()
+    declared = set(re.findall(r"\b(szh?_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sz_config", "sz_stats", "sz_engine", "szh_game"}
+    lib = N.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared <= set(N.EXPORTS) | {"sz_error_string"}
