@@ -133,9 +133,12 @@ class Board:
         return cls(lib().oc_board_from_fen(fen.encode(), int(chess960)))
 
     def __del__(self):
-        if getattr(self, "_own", False) and self._p:
-            lib().oc_board_free(self._p)
-            self._p = None
+        try:
+            if getattr(self, "_own", False) and self._p:
+                lib().oc_board_free(self._p)
+                self._p = None
+        except Exception:
+            pass
 
     def legal_moves(self):
         buf = (Move * MAX_MOVES)()
@@ -193,9 +196,12 @@ class ChessTensor:
         return cls(ptr=lib().oc_ct_from_board(lib().oc_board_from_fen(fen.encode(), int(chess960))))
 
     def __del__(self):
-        if self._p:
-            lib().oc_ct_free(self._p)
-            self._p = None
+        try:
+            if self._p:
+                lib().oc_ct_free(self._p)
+                self._p = None
+        except Exception:
+            pass
 
     @property
     def board(self):
@@ -277,9 +283,12 @@ class Search:
         return cls(ct._p, lib().CHESS_VT, keep=ct, **kw)
 
     def __del__(self):
-        if self._s:
-            lib().oc_search_free(self._s)
-            self._s = None
+        try:
+            if self._s:
+                lib().oc_search_free(self._s)
+                self._s = None
+        except Exception:
+            pass
 
     def advance(self): return bool(lib().oc_search_advance(self._s))
 

@@ -489,7 +489,7 @@ SZ_HD u64 sz_aux_plane(const SzPos& leaf, int j /* 0..6 */) {
         case 3: v = own_q; break;
         case 4: v = opp_k; break;
         case 5: v = opp_q; break;
-        default: v = szm_half(leaf.meta) > 0; break;
+        default: v = ply > 0 && szm_half(leaf.meta) > 0; break;        // start_board(): no_progress plane starts at 0
     }
     return v ? ~0ULL : 0ULL;
 }

@@ -24,7 +24,7 @@ FENS = [
     "6k1/5ppp/8/8/8/8/5PPP/R5K1 w - - 0 1",           # back-rank mate in one
     "8/P7/8/8/8/8/7k/K7 w - - 0 1",                   # promotions (queen + under-promotions)
     "4k3/8/8/8/8/8/8/4K2R w K - 0 1",                 # castling with few pieces
-    "8/8/4k3/8/8/3KR3/8/8 w - - 140 100",             # 75-move rule inside the tree
+    "8/8/5k2/8/8/3KR3/8/8 w - - 140 100",             # 75-move rule inside the tree
 ]
 
 
@@ -75,7 +75,12 @@ def lockstep_search(boards, S, learning, evaluator, c960=False, dtype=torch.floa
         for b, m in enumerate(boards):
             if not pending[b]:
                 continue
-            assert np.array_equal(planes[b].astype(np.uint8), m.search.leaf_planes()), "step %d board %d planes" % (step, b)
+            want = m.search.leaf_planes()
+            got = planes[b].astype(np.uint8)
+            if not np.array_equal(got, want):
+                bad = [c for c in range(119) if not np.array_equal(got[c], want[c])]
+                raise AssertionError("step %d board %d planes differ at %s (depth %d, oracle trace %s)"
+                                     % (step, b, bad, depth[b], m.search.trace()))
             legal = m.search.leaf_actions()
             mine = [p * 64 + v for p in range(73) for v in range(64) if (int(mask[b, p]) >> v) & 1]
             assert mine == legal, "step %d board %d legal mask" % (step, b)

@@ -89,7 +89,7 @@ def test_fivefold_and_seventyfive():
             assert not ct.board.is_game_over()
             ct.move_piece(sz.Move.from_uci(u))
     assert ct.board.is_game_over() and ct.board.result() == "1/2-1/2" and ct.board.outcome().termination == 5
-    ct = sz.ChessTensor(fen="8/8/4k3/8/8/3KR3/8/8 w - - 149 100")
+    ct = sz.ChessTensor(fen="8/8/5k2/8/8/3KR3/8/8 w - - 149 100")
     assert not ct.board.is_game_over()
     ct.move_piece(sz.Move.from_uci("e3e4"))
     assert ct.board.is_game_over() and ct.board.outcome().termination == 4
@@ -132,3 +132,26 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared <= set(N.EXPORTS) | {"sz_error_string"}
+
+
+FENS = [
+    "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1",
+    "rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8",
+    "8/P7/8/8/8/8/7k/K7 w - - 0 1",
+    "8/8/4k3/8/8/3KR3/8/8 b - - 140 100",
+    "r3k2r/8/8/8/8/8/8/R3K2R b KQkq - 3 20",
+]
+
+
+@pytest.mark.parametrize("fen", FENS)
+def test_fen_positions_match_oracle(fen):
+    rng = random.Random(hash(fen) & 0xFFFF)
+    ct = sz.ChessTensor(fen=fen)
+    oct_ = O.ChessTensor.from_fen(fen)
+    for ply in range(60):
+        if _compare_state(ct, oct_, "%s ply %d" % (fen, ply)):
+            break
+        idx, moves = oct_.legal_action_indices()
+        k = rng.randrange(len(idx))
+        ct.push_action(idx[k])
+        oct_.move_piece(moves[k])

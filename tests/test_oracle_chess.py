@@ -97,8 +97,8 @@ def test_terminal_kinds():
     assert O.Board.from_fen("8/8/4k3/8/8/3KNN2/8/8 w - - 0 1").outcome()[0] == 0        # KNN v K is not automatic
     assert O.Board.from_fen("8/8/4kb2/8/8/3BK3/8/8 w - - 0 1").outcome()[0] == 0        # opposite-colour bishops (f6 dark, d3 light)
     assert O.Board.from_fen("8/8/4kb2/8/8/3KB3/8/8 w - - 0 1").outcome() == (2, -1)     # same-colour bishops (f6, e3 dark)
-    assert O.Board.from_fen("8/8/4k3/8/8/3KR3/8/8 w - - 149 100").outcome()[0] == 0
-    assert O.Board.from_fen("8/8/4k3/8/8/3KR3/8/8 w - - 150 100").outcome() == (4, -1)  # 75-move rule
+    assert O.Board.from_fen("8/8/5k2/8/8/3KR3/8/8 w - - 149 100").outcome()[0] == 0
+    assert O.Board.from_fen("8/8/5k2/8/8/3KR3/8/8 w - - 150 100").outcome() == (4, -1)  # 75-move rule
 
 
 def test_en_passant_legality_in_key():
