@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS simulations/sec of batched self-play (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W          (driver contract)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete self-play ply of the hot path over one batch of boards: for every board a full
+MCTS0.search (num_searches simulations: select -> move -> terminal test -> encode -> policy/value net ->
+expand -> backprop), then the visit-count readout, move sampling and move application (sim.py:46-76).
+Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on): 4096 concurrent
+classical-chess boards per GPU, num_searches=800, bf16 policy/value network with seeded random-init weights.
+Boards are independent, so with N ranks each rank owns 4096 boards (weak scaling, no data-path collective).
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline      the hand-written HIP kernel that does the tree work (k_search_step), HBM-bound:
+                algorithmic bytes per launch / measured mean launch duration (HIP events on the launch stream)
+  roofline_nn   the policy/value network forward (MFMA-bound): 2.915 GFLOP x boards / mean forward duration
+  cpu_baseline  the oracle (reference algorithm restated on the CPU: one leaf per step, per-game pointer tree,
+                batch-1 fp32 forward on the host cores), timed on rank 0 over a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def tree_bytes_per_launch(boards, sims, expansions, sum_depth, sum_children, plane_bytes):
+    """Algorithmic HBM bytes of one k_search_step launch, from the measured mean depth / fan-out.
+    per simulation:   select   d*(16*K + 16)      child stat spans (W f64, N i32, P f32) + one 16-B meta per level
+                      backprop (d+1)*24           N,W read + write per level
+    per expansion:    position 80 + 80            parent record read, child record write
+                      history  7*64 + 150*16/8    ancestors for planes; key/meta window for repetition (mean clock ~ small)
+                      planes   119*64*plane_bytes network input written
+                      mask     584*2              legal-move mask written, re-read after the network
+                      policy   4*K                legal probabilities gathered (+4 value)
+                      children 32*K               EdgeStat + EdgeMeta written
+                      path     8*(d+1)            descent path spilled and re-read
+    """
+    if sims == 0:
+        return 0.0
+    d = sum_depth / sims
+    k = sum_children / max(expansions, 1)
+    per_sim = d * (16.0 * k + 16.0) + (d + 1.0) * 24.0
+    per_exp = 160.0 + 7 * 64.0 + 64.0 + 119 * 64 * plane_bytes + 584 * 2 + 4.0 * k + 4.0 + 32.0 * k + 8.0 * (d + 1.0)
+    return per_sim * sims + per_exp * expansions
+
+
+def cpu_baseline(num_searches, budget_s=15.0):
+    """Reference algorithm on the host cores: oracle search (per-game tree, one leaf per step) + batch-1 fp32 forward."""
+    import sigma_zero_amd as sz
+    from oracle import oracle as O
+    # the GPU box exposes every host core but grants one GPU job a 16-core share; oversubscribing 256 threads
+    # on a batch-1 forward is ~1000x slower, so use the share (and say so in `cores`)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = sz.policyNN({}).eval()
+    game = O.ChessTensor()
+    S = min(num_searches, 100)
+    sims = 0
+    rng = np.random.RandomState(0)
+    t0 = time.perf_counter()
+    plies = 0
+    with torch.no_grad():
+        while time.perf_counter() - t0 < budget_s:
+            s = O.Search.on_chess(game, c=2.0, num_searches=S, learning=True)
+            while s.advance():
+                x = torch.from_numpy(s.leaf_planes().astype(np.float32)).unsqueeze(0)
+                p, v = net(x, inference=True)
+                s.feed(p[0].numpy(), float(v[0, 0]))
+                if time.perf_counter() - t0 > budget_s * 1.5:
+                    break
+            e, t = s.counters()
+            sims += e + t
+            idx, vis, moves = s.root_children()
+            if sum(vis) == 0 or game.get_value_and_terminated()[1]:
+                break
+            game.move_piece(moves[O.sample_move(vis, rng.random_sample())])
+            plies += 1
+            if game.get_value_and_terminated()[1]:
+                game = O.ChessTensor()
+    dt = time.perf_counter() - t0
+    return {"value": sims / dt, "unit": "simulations/s", "cores": cores, "kind": "port",
+            "sample": "1 self-play game from the classical start position, num_searches=%d, fp32 batch-1 forward, %d plies / %d simulations in %.1f s"
+                      % (S, plies, sims, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--boards", type=int, default=4096, help="boards per GPU")
+    ap.add_argument("--searches", type=int, default=800)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--chess960", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the search path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import sigma_zero_amd as sz
+    from sigma_zero_amd.selfplay import SelfPlayEngine
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
+    B, S = a.boards, a.searches
+    eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype)
+    rng = np.random.RandomState(1234 + rank)
+    import random
+    prng = random.Random(rank)
+    eng.new_games([prng.randrange(960) if a.chess960 else -1 for _ in range(B)])
+
+    ev_nn, ev_tree = [], []
+    use_events = not a.no_kernel_events
+
+    def evaluate(planes):
+        x = planes.contiguous(memory_format=torch.channels_last)
+        policy, value = model(x, inference=True)
+        return policy.float().contiguous(), value.float().reshape(-1).contiguous()
+
+    @torch.no_grad()
+    def one_ply(timed):
+        eng.begin()
+        for _ in range(S):
+            if timed and use_events:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                policy, value = evaluate(eng.planes)
+                e1.record()
+                eng.step(policy, value)
+                e2.record()
+                ev_nn.append((e0, e1)); ev_tree.append((e1, e2))
+            else:
+                policy, value = evaluate(eng.planes)
+                eng.step(policy, value)
+        eng.play(rng.random_sample(B))
+        rec = eng.fetch_ply()               # the training record of this ply goes to the host like in sim.py:71-73
+        # finished games restart so that every board keeps working (steady-state self-play)
+        over = rec["game_over"].astype(bool) & rec["active"].astype(bool)
+        if over.any():
+            eng.new_games([prng.randrange(960) if a.chess960 else -1 for _ in range(B)], active=over.astype(np.uint8))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        one_ply(False)
+    st0 = eng.check_errors()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_ply(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    st1 = eng.check_errors()
+
+    sims = st1["simulations"] - st0["simulations"]
+    exps = st1["expansions"] - st0["expansions"]
+    sum_depth = st1["sum_depth"] - st0["sum_depth"]
+    sum_k = st1["sum_children"] - st0["sum_children"]
+    tot = torch.tensor([float(sims), float(exps), dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max = float(mx[2])
+    else:
+        dt_max = dt
+    total_sims, total_exps = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        out = {
+            "metric": "MCTS simulations/sec (self-play)", "value": total_sims / dt_max, "unit": "simulations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / max(a.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "data": "synthetic (seeded random-init policyNN weights, self-play from %s start positions)" % ("Chess960" if a.chess960 else "classical"),
+            "config": {"workload": "selfplay_%dboards_%dsearches" % (B, S), "boards_per_gpu": B, "num_searches": S, "C": 2,
+                       "learning": True, "chess960": bool(a.chess960), "step": "one ply = full search of every board + sample + play",
+                       "parallelism": "games sharded, %d rank(s), no data-path collective" % world},
+            "expansions_per_s": total_exps / dt_max,
+            "mean_leaf_depth": sum_depth / max(sims, 1), "mean_children": sum_k / max(exps, 1),
+            "max_edges_used": st1["max_edges_used"],
+        }
+        if use_events and ev_tree:
+            tree_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_tree]))
+            nn_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_nn]))
+            launches = len(ev_tree)
+            plane_bytes = 2 if dtype == torch.bfloat16 else 4
+            bytes_per_launch = tree_bytes_per_launch(B, sims, exps, sum_depth, sum_k, plane_bytes) / launches
+            ach = bytes_per_launch / (tree_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": tree_ms,
+                               "algorithmic_bytes_per_launch": bytes_per_launch}
+            fl = exps / launches * sz.network.FLOPS_PER_BOARD
+            tf = fl / (nn_ms * 1e-3) / 1e12
+            out["roofline_nn"] = {"kernel": "policyNN forward (MIOpen/hipBLASLt kernels, bf16 channels_last)", "bound": "mfma", "achieved": tf,
+                                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                                  "forward_ms": nn_ms, "useful_boards_per_forward": exps / launches}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
