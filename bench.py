@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--searches", type=int, default=800)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chess960", type=int, default=0)
+    ap.add_argument("--net", default="fast", choices=["fast", "torch"],
+                    help="fast: hand-written MFMA conv tower (csrc/sz_nn.hip); torch: MIOpen/ATen kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
@@ -130,18 +132,27 @@ def main():
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
+    fast = a.net == "fast" and dtype == torch.bfloat16
     B, S = a.boards, a.searches
-    eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype)
+    if fast:
+        from sigma_zero_amd.fastnet import FastPolicyNet
+        model = FastPolicyNet(sz.policyNN({}).eval(), device=dev)
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype="nhwc128")
+    else:
+        model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype)
     rng = np.random.RandomState(1234 + rank)
     import random
     prng = random.Random(rank)
     eng.new_games([prng.randrange(960) if a.chess960 else -1 for _ in range(B)])
 
-    ev_nn, ev_tree = [], []
+    ev_nn, ev_tree, conv_events = [], [], []
     use_events = not a.no_kernel_events
 
     def evaluate(planes):
+        if fast:
+            policy, value = model(planes, inference=True)
+            return policy, value.reshape(-1)
         x = planes.contiguous(memory_format=torch.channels_last)
         policy, value = model(x, inference=True)
         return policy.float().contiguous(), value.float().reshape(-1).contiguous()
@@ -149,7 +160,10 @@ def main():
     @torch.no_grad()
     def one_ply(timed):
         eng.begin()
-        for _ in range(S):
+        for it in range(S):
+            if fast:
+                # sample the conv kernel's own launch duration on every 50th iteration (HIP events on the launch stream)
+                model.timing = conv_events if (timed and use_events and it % 50 == 25) else None
             if timed and use_events:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -218,14 +232,34 @@ def main():
             plane_bytes = 2 if dtype == torch.bfloat16 else 4
             bytes_per_launch = tree_bytes_per_launch(B, sims, exps, sum_depth, sum_k, plane_bytes) / launches
             ach = bytes_per_launch / (tree_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": tree_ms,
-                               "algorithmic_bytes_per_launch": bytes_per_launch}
+            tree_roof = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": tree_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step_time": tree_ms / (tree_ms + nn_ms)}
             fl = exps / launches * sz.network.FLOPS_PER_BOARD
             tf = fl / (nn_ms * 1e-3) / 1e12
-            out["roofline_nn"] = {"kernel": "policyNN forward (MIOpen/hipBLASLt kernels, bf16 channels_last)", "bound": "mfma", "achieved": tf,
-                                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
-                                  "forward_ms": nn_ms, "useful_boards_per_forward": exps / launches}
+            nn_roof = {"kernel": "policyNN forward, all kernels (%s)" % ("sz_nn.hip MFMA tower + torch heads" if fast else "MIOpen/ATen, bf16 channels_last"),
+                       "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                       "forward_ms": nn_ms, "useful_boards_per_forward": exps / launches}
+            if fast and conv_events:
+                # dominant kernel of the whole job: k_conv_bf16<256,9> (38 of the 41 tower launches, >90 % of GPU time)
+                conv_ms = float(np.mean([s.elapsed_time(e) for s, e in conv_events]))
+                conv_flop = 2.0 * B * 64 * 256 * 2304
+                ctf = conv_flop / (conv_ms * 1e-3) / 1e12
+                traffic = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "pmc_conv_latest.json")) as f:
+                        traffic = json.load(f)
+                except Exception:
+                    pass
+                out["roofline"] = {"kernel": "k_conv_bf16<256,9> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
+                                   "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
+                                   "launch_ms": conv_ms, "algorithmic_flop_per_launch": conv_flop, "sampled_launches": len(conv_events),
+                                   "traffic": traffic}
+                out["roofline_tree"] = tree_roof
+                out["roofline_nn"] = nn_roof
+            else:
+                out["roofline"] = tree_roof
+                out["roofline_nn"] = nn_roof
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out))

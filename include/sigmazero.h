@@ -34,7 +34,10 @@ enum {
     SZ_ERR_ZERO_VISITS = -6      /* num_searches == 1: the reference raises ZeroDivisionError (mcts.py:118-120) */
 };
 
-enum { SZ_PLANES_F32 = 0, SZ_PLANES_BF16 = 1 };
+/* network-input layouts written by the engine:
+ *   F32 / BF16     : [n_boards,119,8,8] NCHW, the reference's get_representation() layout
+ *   NHWC128_BF16   : [n_boards,64,128] position-major, channels 119..127 zero — input of sz_nn_conv_bf16 (stem) */
+enum { SZ_PLANES_F32 = 0, SZ_PLANES_BF16 = 1, SZ_PLANES_NHWC128_BF16 = 2 };
 
 /* ------------------------------------------------------------------ engine (HIP, gfx950) */
 
@@ -123,6 +126,16 @@ int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_no
                      int32_t* status, void* stream);
 /* copy one board's current game position record (SZ_POS_BYTES) to the host */
 int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, void* stream);
+
+/* ------------------------------------------------------------------ network tower (MFMA, gfx950) */
+
+/* One fused layer of policyNN's tower (network.py:36-83 BasicBlock halves, :105 stem, :141 conv_p1):
+ * conv (3x3 pad 1 or 1x1) with BatchNorm folded + bias (+ residual) (+ ReLU); NHWC bf16 in/out, f32 accumulate.
+ * in [n_boards,64,cin] (cin 128 or 256), out/residual [n_boards,64,256], bias [256] f32, w_packed from sz_nn_pack_weights. */
+int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
+                    int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream);
+/* host: torch conv weight [256,cin_real,k,k] f32 -> MFMA fragment order [k*k][cin_padded/16][8][64][8] bf16 */
+int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
 
 const char* sz_error_string(int code);
 int sz_device_count(void);

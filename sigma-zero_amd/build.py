@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsigmazero_hip.so")
-SOURCES = ["sz_engine.hip", "sz_host.cpp"]
+SOURCES = ["sz_engine.hip", "sz_nn.hip", "sz_host.cpp"]
 HEADERS = [os.path.join(CSRC, "sz_chess.h"), os.path.join(PKG, "..", "include", "sigmazero.h")]
 # -ffp-contract=off: the UCB / prior arithmetic must round exactly like the reference's torch ops
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function"]

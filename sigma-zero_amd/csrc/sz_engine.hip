@@ -78,6 +78,9 @@ __device__ __forceinline__ float wave_sum_butterfly(float v) {
     for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
     return v;
 }
+__device__ __forceinline__ size_t planes_board_bytes(int dtype) {
+    return dtype == SZ_PLANES_F32 ? (size_t)SZ_NUM_PLANES * 64 * 4 : (dtype == SZ_PLANES_BF16 ? (size_t)SZ_NUM_PLANES * 64 * 2 : (size_t)64 * 128 * 2);
+}
 // lane-indexed ballot (bit v = view square v) -> real-square bitboard
 __device__ __forceinline__ u64 view_to_squares(u64 m, int white) {
     return white ? __builtin_bswap64(m) : __builtin_bswap64(sz_brev(m));
@@ -194,6 +197,30 @@ __device__ void wave_load_history(const BoardPtrs& bp, const int* path, int D, i
 __device__ void wave_encode(const u64* hist_lds, const SzPos& X, void* out_board, int dtype, uint8_t* packed_out) {
     const int lane = lane_id();
     const int vw = szm_turn(X.meta);
+    if (dtype == SZ_PLANES_NHWC128_BF16 && out_board) {
+        // NHWC for the custom MFMA stem: lane = position, 128 channels (119 real) = 16 stores of 8 channels
+        const int s = lane ^ sz_view_flip(vw);
+        uint4* dst = (uint4*)out_board + lane * 16;
+        for (int q = 0; q < 16; q++) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = q * 8 + k;
+                if (c < SZ_NUM_PLANES) {
+                    u64 bb = (c < 112) ? sz_hist_plane(hist_lds + (c / 14) * 8, c % 14, vw) : sz_aux_plane(X, c - 112);
+                    bits |= (uint32_t)((bb >> s) & 1) << k;
+                }
+            }
+            uint4 o;
+            o.x = ((bits & 1) ? 0x3F80u : 0u) | ((bits & 2) ? 0x3F800000u : 0u);
+            o.y = ((bits & 4) ? 0x3F80u : 0u) | ((bits & 8) ? 0x3F800000u : 0u);
+            o.z = ((bits & 16) ? 0x3F80u : 0u) | ((bits & 32) ? 0x3F800000u : 0u);
+            o.w = ((bits & 64) ? 0x3F80u : 0u) | ((bits & 128) ? 0x3F800000u : 0u);
+            dst[q] = o;
+        }
+        if (!packed_out) return;
+        out_board = nullptr;
+    }
     const int r = lane & 7;
     for (int i = 0; i < 15; i++) {
         int c = i * 8 + (lane >> 3);
@@ -328,8 +355,7 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
     for (int i = lane; i < SZ_MASK_WORDS; i += 64) bp.pmask[i] = mask[i];
     wave_load_history(bp, path, 0, root_ply, X, hist);
     __syncthreads();
-    size_t esz = v.planes_dtype == SZ_PLANES_F32 ? 4 : 2;
-    wave_encode(hist, X, planes ? (char*)planes + (size_t)b * SZ_NUM_PLANES * 64 * esz : nullptr, v.planes_dtype,
+    wave_encode(hist, X, planes ? (char*)planes + (size_t)b * planes_board_bytes(v.planes_dtype) : nullptr, v.planes_dtype,
                 v.rec_planes ? v.rec_planes + (size_t)b * SZ_NUM_PLANES * 8 : nullptr);
     if (lane == 0) {
         Ctl* c = bp.ctl;
@@ -464,8 +490,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         for (int j = lane; j <= d; j += 64) bp.gpath[j] = path[j];
         wave_load_history(bp, path, d, root_ply, X, hist);
         __syncthreads();
-        size_t esz = v.planes_dtype == SZ_PLANES_F32 ? 4 : 2;
-        wave_encode(hist, X, (char*)planes + (size_t)b * SZ_NUM_PLANES * 64 * esz, v.planes_dtype, nullptr);
+        wave_encode(hist, X, (char*)planes + (size_t)b * planes_board_bytes(v.planes_dtype), v.planes_dtype, nullptr);
         status |= ST_PENDING;
         if (lane == 0) { bp.ctl->pend_node = nid; bp.ctl->pend_depth = d; }
         break;

@@ -1,0 +1,224 @@
+// sz_nn.hip — hand-written CDNA4 MFMA convolution for the policy/value tower of the reference
+// (/root/reference/network.py:36-83 BasicBlock, :105-137 policyNN stem/tower).
+//
+// conv3x3(pad 1) over 8x8 boards, NHWC bf16, C_out = 256, C_in in {128 (zero-padded stem), 256},
+// with BatchNorm folded into weights/bias (eval mode) and bias + ReLU (+ residual add) fused in the
+// epilogue — one launch replaces MIOpen's igemm + batch_norm + clamp + add kernels of a BasicBlock half.
+//
+// MI355X mapping (not a warp-tiling port):
+//   * one workgroup = 4 waves (one per SIMD) = 4 boards = 256 output positions x 256 output channels;
+//     the 4 boards' activations (256 pos x C_in) are loaded ONCE from HBM into LDS (row pitch C_in*2+16 B:
+//     conflict-free ds_read_b128) and stay resident for all 9 taps — the im2col matrix is never formed,
+//     a tap is just a per-lane row address (off-board taps read a zero row);
+//   * D = W x Act^T on v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows = out channels)
+//     and activations as the B operand (cols = positions): each lane then owns 4 consecutive output
+//     channels of one position per register quad -> 8-byte NHWC stores, residual read in the same shape;
+//   * each wave owns 128 channels x 128 positions (4x4 MFMA tiles, 256 accumulator VGPRs, 1 wave/SIMD);
+//   * weights are pre-packed on the host in exact fragment order [tap][kstep][co_tile][lane][8], so a
+//     weight fragment is one fully coalesced 1 KiB global_load_dwordx4 from L2 (1.18 MB/layer stays
+//     L2-resident), prefetched 2 k-steps ahead through a 4-deep register ring: the K loop has NO barrier.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/sigmazero.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define NN_WG_BOARDS 4
+#define NN_COUT 256
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    // round-to-nearest-even via the hardware convert (v_cvt_pk_bf16_f32)
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    uint16_t xb = __builtin_bit_cast(uint16_t, x), yb = __builtin_bit_cast(uint16_t, y);
+    return (uint32_t)xb | ((uint32_t)yb << 16);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+
+// in  : [n_boards][64][CIN]  bf16 (NHWC)            w : packed fragments (see sz_nn_pack_weights)
+// out : [n_boards][64][256]  bf16 (NHWC)            bias : [256] f32 (BN folded)
+// res : optional residual, same layout as out; relu: apply max(0, .) last
+template <int CIN, int NTAPS>
+__global__ __launch_bounds__(256, 1) void k_conv_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w, const float* __restrict__ bias,
+                                                      const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int relu) {
+    constexpr int PITCH = CIN * 2 + 16;                  // bytes per position row in LDS
+    constexpr int KSTEPS = CIN / 16;                     // k-steps (16 channels) per tap
+    constexpr int ZERO_ROW = NN_WG_BOARDS * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1;              // channel half, position half (2 boards)
+    const int board0 = blockIdx.x * NN_WG_BOARDS;
+
+    // ---- stage the 4 boards' activations into LDS (coalesced 16-B loads), plus one zero row ----
+    {
+        constexpr int CHUNKS_PER_POS = CIN / 8;           // 16-B chunks per position
+        constexpr int TOTAL = NN_WG_BOARDS * 64 * CHUNKS_PER_POS;
+        const uint4* src = (const uint4*)(in + (size_t)board0 * 64 * CIN);
+        const int valid_boards = min(NN_WG_BOARDS, n_boards - board0);
+        const int valid_chunks = valid_boards * 64 * CHUNKS_PER_POS;
+#pragma unroll 4
+        for (int c = tid; c < TOTAL; c += 256) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < valid_chunks) v = src[c];
+            int pos = c / CHUNKS_PER_POS, ch = c % CHUNKS_PER_POS;
+            *(uint4*)(lds + pos * PITCH + ch * 16) = v;
+        }
+        for (int c = tid; c < PITCH / 16; c += 256) *(uint4*)(lds + ZERO_ROW * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // per-lane geometry: lane owns position p32 of each 32-position tile; half h selects k 8..15
+    const int p32 = lane & 31, h = lane >> 5;
+    // weight fragment stream of this wave: [tap][kstep][co_tile 0..7][lane] (uint4 = 8 bf16)
+    const uint4* wbase = w + (size_t)(wc * 4) * 64 + lane;
+    constexpr int W_KSTEP_STRIDE = 8 * 64;                // uint4 per (tap,kstep)
+
+    uint4 aring[4][4];                                     // 4-deep ring x 4 co tiles
+    constexpr int TOTAL_KS = NTAPS * KSTEPS;
+    // prologue: prefetch k-steps 0 and 1
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
+
+    // LDS byte address of this lane's activation row for (tap, position tile j); off-board taps -> zero row
+    auto tap_addr = [&](int tap, int j) -> int {
+        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
+        int pos = (j & 1) * 32 + p32;                     // position inside its board
+        int y = (pos >> 3) + dy, x = (pos & 7) + dx;
+        bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
+        int row = ok ? ((wp * 2 + (j >> 1)) * 64 + y * 8 + x) : ZERO_ROW;
+        return row * PITCH + h * 16;
+    };
+    int bcur[4], bnxt[4];
+    bf16x8 bfrag[2][4];                                    // activations double-buffered one k-step ahead
+#pragma unroll
+    for (int j = 0; j < 4; j++) { bcur[j] = tap_addr(0, j); bnxt[j] = bcur[j]; bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]); }
+
+    // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches to their uses:
+    //   issue { weights of k-step ks+2 (L2 -> ring), activations of ks+1 (LDS -> bfrag) } ; 16 MFMAs of ks.
+    // The compiler's own s_waitcnt then becomes counted (vmcnt(8)/lgkmcnt(4)): loads stay in flight under the MFMAs.
+    for (int tap = 0; tap < NTAPS; tap++) {
+        if (tap + 1 < NTAPS) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bnxt[j] = tap_addr(tap + 1, j);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KSTEPS; kc++) {
+            const int ks = tap * KSTEPS + kc;
+            if (ks + 2 < TOTAL_KS) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) aring[(kc + 2) & 3][i] = wbase[(size_t)(ks + 2) * W_KSTEP_STRIDE + i * 64];
+            }
+            if (kc + 1 < KSTEPS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 32);
+            } else if (tap + 1 < NTAPS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bnxt[j]);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & 3][i]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) bcur[j] = bnxt[j];
+    }
+
+    // ---- epilogue: + bias (+ residual), ReLU, bf16, 8-byte NHWC stores --------------------------
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int board = board0 + wp * 2 + (j >> 1);
+        if (board >= n_boards) continue;
+        const int pos = (j & 1) * 32 + p32;
+        const size_t rowoff = ((size_t)board * 64 + pos) * NN_COUT;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = wc * 128 + i * 32 + 8 * g + 4 * h;
+                f32x4 b4 = *(const f32x4*)(bias + co);
+                float v0 = acc[i][j][4 * g + 0] + b4[0], v1 = acc[i][j][4 * g + 1] + b4[1];
+                float v2 = acc[i][j][4 * g + 2] + b4[2], v3 = acc[i][j][4 * g + 3] + b4[3];
+                if (res) {
+                    uint2 r = *(const uint2*)(res + rowoff + co);
+                    v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
+                }
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                *(uint2*)(out + rowoff + co) = o;
+            }
+        }
+    }
+}
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
+
+template <int CIN, int NTAPS> static int launch_conv(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int relu, hipStream_t s) {
+    constexpr int PITCH = CIN * 2 + 16;
+    const size_t lds = (size_t)(NN_WG_BOARDS * 64 + 1) * PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (n_boards + NN_WG_BOARDS - 1) / NN_WG_BOARDS;
+    hipLaunchKernelGGL((k_conv_bf16<CIN, NTAPS>), dim3(grid), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias, (const uint16_t*)res, (uint16_t*)out, n_boards, relu);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+extern "C" {
+
+// Fused conv (+folded BN) + bias (+ residual) (+ ReLU), NHWC bf16, C_out = 256.
+//   ksize 3: 3x3 pad 1 (network.py:17-29 conv3x3) ; ksize 1: 1x1 (network.py:32-34 conv1x1)
+//   cin: 128 (stem, channels >= 119 are zero) or 256.
+int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
+                    int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream) {
+    if (!in || !w_packed || !bias || !out || n_boards <= 0) return SZ_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (ksize == 3 && cin == 256) return launch_conv<256, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    if (ksize == 3 && cin == 128) return launch_conv<128, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    if (ksize == 1 && cin == 256) return launch_conv<256, 1>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    return SZ_ERR_INVALID;
+}
+
+// Host-side weight packing into MFMA A-fragment order.
+//   w_in : [256 co][cin_real][k][k] f32 (torch conv weight, BN already folded by the caller)
+//   out  : [taps][cin/16 ksteps][8 co tiles][64 lanes][8] bf16 ;  lane l, elem j <- w[co = tile*32 + (l&31)][ci = kstep*16 + 8*(l>>5) + j]
+int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out) {
+    if (!w_in || !out || (ksize != 1 && ksize != 3) || cin_padded % 16 || cin_real > cin_padded) return SZ_ERR_INVALID;
+    const int taps = ksize * ksize, ksteps = cin_padded / 16;
+    for (int t = 0; t < taps; t++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int tile = 0; tile < 8; tile++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        int co = tile * 32 + (l & 31), ci = ks * 16 + 8 * (l >> 5) + j;
+                        float v = (ci < cin_real) ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
+                        uint32_t u; memcpy(&u, &v, 4);
+                        uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);            // RNE (weights are finite)
+                        out[((((size_t)t * ksteps + ks) * 8 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
+                    }
+    return SZ_OK;
+}
+
+}  // extern "C"

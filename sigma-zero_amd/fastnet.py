@@ -1,0 +1,120 @@
+"""Inference form of policyNN (network.py) on the hand-written CDNA4 MFMA convolution (csrc/sz_nn.hip).
+
+BatchNorm (eval mode) is folded into the convolution weights and a per-channel bias; every tower layer is ONE
+launch of `sz_nn_conv_bf16` (conv + bias + optional residual + ReLU, NHWC bf16, f32 accumulate).  The 39 tower
+convolutions and conv_p1 run on the custom kernel; the two tiny heads (256->73 1x1, value MLP) stay in torch.
+Input: the engine's NHWC planes [B, 64, 128] bf16 (119 real channels, the rest zero).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _fold_bn(conv_w, bn, conv_b=None):
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    w = conv_w.detach().double() * scale.view(-1, 1, 1, 1)
+    b = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    if conv_b is not None:
+        b = b + conv_b.detach().double() * scale
+    return w.float(), b.float()
+
+
+def _pack(w, cin_padded, ksize, device):
+    """[256, cin, k, k] f32 -> MFMA A-fragment order (uint16 bf16 bits) on `device`."""
+    w = w.contiguous().cpu().float().numpy()
+    co, cin = w.shape[0], w.shape[1]
+    assert co == 256
+    out = np.zeros(ksize * ksize * (cin_padded // 16) * 8 * 64 * 8, dtype=np.uint16)
+    N.check(N.lib().sz_nn_pack_weights(w.ctypes.data_as(C.c_void_p), cin, cin_padded, ksize, out.ctypes.data_as(C.c_void_p)), "sz_nn_pack_weights")
+    return torch.from_numpy(out.view(np.int16)).to(device)
+
+
+class FastPolicyNet:
+    def __init__(self, model, device="cuda:0"):
+        model = model.eval()
+        self.device = torch.device(device)
+        dev = self.device
+        self.layers = []          # (packed_w, bias, cin, ksize)
+        w, b = _fold_bn(model.conv1.weight, model.norm_layer)
+        self.stem = (_pack(w, 128, 3, dev), b.to(dev).contiguous())
+        self.blocks = []
+        for blk in model.resnet_blocks:
+            w1, b1 = _fold_bn(blk.conv1.weight, blk.bn1)
+            w2, b2 = _fold_bn(blk.conv2.weight, blk.bn2)
+            self.blocks.append((_pack(w1, 256, 3, dev), b1.to(dev).contiguous(), _pack(w2, 256, 3, dev), b2.to(dev).contiguous()))
+        wp, bp = _fold_bn(model.conv_p1.weight, model.p_norm1)
+        self.p1 = (_pack(wp, 256, 1, dev), bp.to(dev).contiguous())
+        # heads (tiny): policy 1x1 256->73 (+bias), value 1x1 256->1 + BN + ReLU + MLP
+        self.wp2 = model.conv_p2.weight.detach().view(73, 256).t().contiguous().to(dev).to(torch.bfloat16)      # [256,73]
+        self.bp2 = model.conv_p2.bias.detach().float().to(dev)
+        wv, bv = _fold_bn(model.conv_v1.weight, model.v_norm)
+        self.wv = wv.view(1, 256).t().contiguous().to(dev).to(torch.bfloat16)                                    # [256,1]
+        self.bv = bv.to(dev)
+        self.fc1_w = model.fc_v1.weight.detach().float().t().contiguous().to(dev)
+        self.fc1_b = model.fc_v1.bias.detach().float().to(dev)
+        self.fc2_w = model.fc_v2.weight.detach().float().t().contiguous().to(dev)
+        self.fc2_b = model.fc_v2.bias.detach().float().to(dev)
+        self._bufs = {}
+        self.timing = None          # optional list: (start, end) HIP event pairs around every 3x3 C_in=256 conv launch
+
+    def parameters(self):
+        return iter([self.wp2])        # dtype probe used by callers (bf16)
+
+    def to(self, *a, **k):
+        return self
+
+    def _buffers(self, B):
+        if B not in self._bufs:
+            self._bufs[B] = [torch.empty(B, 64, 256, dtype=torch.bfloat16, device=self.device) for _ in range(3)]
+        return self._bufs[B]
+
+    def _conv(self, x, w, b, res, out, B, cin, ksize, relu=1):
+        ev = None
+        if self.timing is not None and cin == 256 and ksize == 3:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self._launch(x, w, b, res, out, B, cin, ksize, relu)
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+
+    def _launch(self, x, w, b, res, out, B, cin, ksize, relu):
+        N.check(N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                                        C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(out.data_ptr()),
+                                        B, cin, ksize, relu, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_conv_bf16")
+
+    @torch.no_grad()
+    def tower(self, planes):
+        """planes [B,64,128] bf16 NHWC -> tower output [B,64,256] bf16 NHWC"""
+        B = planes.shape[0]
+        a, t, c = self._buffers(B)
+        self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3)
+        for (w1, b1, w2, b2) in self.blocks:
+            self._conv(a, w1, b1, None, t, B, 256, 3)
+            self._conv(t, w2, b2, a, c, B, 256, 3)
+            a, c = c, a
+        return a, t
+
+    @torch.no_grad()
+    def __call__(self, planes, inference=True):
+        B = planes.shape[0]
+        x, scratch = self.tower(planes)
+        self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
+        logits = torch.matmul(scratch.view(B * 64, 256), self.wp2).float().view(B, 64, 73) + self.bp2        # [B,pos,plane]
+        logits = logits.transpose(1, 2).reshape(B, 73 * 64)                                                  # flatten of [73,8,8]
+        policy = torch.softmax(logits, dim=1) if inference else logits
+        v = torch.relu(torch.matmul(x.view(B * 64, 256), self.wv).float().view(B, 64) + self.bv)
+        v = torch.relu(v @ self.fc1_w + self.fc1_b)
+        value = torch.tanh(v @ self.fc2_w + self.fc2_b)
+        return policy, value
+
+
+def planes_nchw_to_nhwc128(planes):
+    """[B,119,8,8] (any float dtype) -> [B,64,128] bf16, for tests"""
+    B = planes.shape[0]
+    out = torch.zeros(B, 64, 128, dtype=torch.bfloat16, device=planes.device)
+    out[:, :, :119] = planes.reshape(B, 119, 64).transpose(1, 2).to(torch.bfloat16)
+    return out

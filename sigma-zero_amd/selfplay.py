@@ -27,14 +27,20 @@ class SelfPlayEngine:
         self.S = int(args["num_searches"])
         self.chess960 = bool(chess960)
         self.planes_dtype = planes_dtype
+        # planes_dtype: torch.float32 / torch.bfloat16 -> [B,119,8,8] NCHW (reference layout);
+        #               "nhwc128" -> [B,64,128] bf16 position-major for FastPolicyNet (csrc/sz_nn.hip)
+        self.nhwc = planes_dtype == "nhwc128"
+        code = N.SZ_PLANES_NHWC128_BF16 if self.nhwc else (N.SZ_PLANES_BF16 if planes_dtype == torch.bfloat16 else N.SZ_PLANES_F32)
         cfg = N.sz_config(self.B, self.S, float(args["C"]), int(bool(learning)), float(noise_value), int(self.chess960),
-                          int(edges_per_board), N.SZ_PLANES_BF16 if planes_dtype == torch.bfloat16 else N.SZ_PLANES_F32,
-                          self.device.index or 0)
+                          int(edges_per_board), code, self.device.index or 0)
         self._e = C.c_void_p()
         torch.cuda.set_device(self.device)
         N.check(N.lib().sz_create(C.byref(cfg), C.byref(self._e)), "sz_create")
         dev = self.device
-        self.planes = torch.zeros(self.B, N.SZ_PLANES, 8, 8, dtype=planes_dtype, device=dev)
+        if self.nhwc:
+            self.planes = torch.zeros(self.B, 64, 128, dtype=torch.bfloat16, device=dev)
+        else:
+            self.planes = torch.zeros(self.B, N.SZ_PLANES, 8, 8, dtype=planes_dtype, device=dev)
         self.uniforms = torch.zeros(self.B, dtype=torch.float64, device=dev)
         self.root_action = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.int32, device=dev)
         self.root_visits = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.int32, device=dev)

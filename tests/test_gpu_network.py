@@ -1,0 +1,96 @@
+"""The hand-written MFMA convolution (csrc/sz_nn.hip) and FastPolicyNet against plain PyTorch fp32 references.
+Floating point: tolerances are stated per test (bf16 storage, f32 accumulation)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sigma_zero_amd as sz
+from sigma_zero_amd import _native as N
+from sigma_zero_amd.fastnet import FastPolicyNet, _pack, planes_nchw_to_nhwc128
+from sigma_zero_amd.selfplay import SelfPlayEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_conv(x_nhwc, w, bias, res, cin_padded, ksize, relu):
+    B = x_nhwc.shape[0]
+    out = torch.empty(B, 64, 256, dtype=torch.bfloat16, device="cuda")
+    wp = _pack(w, cin_padded, ksize, "cuda")
+    N.check(N.lib().sz_nn_conv_bf16(C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                    C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(out.data_ptr()),
+                                    B, cin_padded, ksize, int(relu), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("B,cin,ksize,use_res,relu", [(4, 256, 3, False, True), (7, 256, 3, True, True), (3, 119, 3, False, True),
+                                                       (5, 256, 1, False, True), (8, 256, 3, True, False), (130, 256, 3, True, True)])
+def test_conv_matches_torch_fp32(B, cin, ksize, use_res, relu):
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + cin + ksize)
+    cin_padded = 128 if cin == 119 else cin
+    x = torch.randn(B, cin, 8, 8, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(256, cin, ksize, ksize, generator=g, device="cuda") * (1.0 / (cin * ksize * ksize) ** 0.5))
+    bias = torch.randn(256, generator=g, device="cuda")
+    res = torch.randn(B, 256, 8, 8, generator=g, device="cuda").to(torch.bfloat16) if use_res else None
+    x_nhwc = torch.zeros(B, 64, cin_padded, dtype=torch.bfloat16, device="cuda")
+    x_nhwc[:, :, :cin] = x.reshape(B, cin, 64).transpose(1, 2)
+    res_nhwc = res.reshape(B, 256, 64).transpose(1, 2).contiguous() if use_res else None
+    out = _run_conv(x_nhwc, w, bias, res_nhwc, cin_padded, ksize, relu)
+    # reference: same bf16-rounded inputs and weights, fp32 math
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), bias, padding=ksize // 2)
+    if use_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    got = out.float().transpose(1, 2).reshape(B, 256, 8, 8)
+    # tolerance: one bf16 rounding of the output (2^-8 relative) + f32 accumulation-order noise over K <= 2304
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-3), float((got - ref).abs().max())
+
+
+def test_fast_network_matches_fp32_policynn():
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    # give BatchNorm non-trivial running statistics so that the folding is exercised
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g, device="cuda") * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g, device="cuda") * 0.1)
+    fast = FastPolicyNet(net)
+    x = (torch.rand(37, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
+    with torch.no_grad():
+        p_ref, v_ref = net(x, inference=True)
+        p, v = fast(planes_nchw_to_nhwc128(x), inference=True)
+    # bf16 activations through 40 layers: policies agree to ~1e-2 relative on probabilities of size ~2e-4
+    assert p.shape == p_ref.shape and torch.allclose(p.sum(1), torch.ones(37, device="cuda"), atol=1e-4)
+    assert float((p - p_ref).abs().max()) < 2e-5, float((p - p_ref).abs().max())
+    assert float((v.reshape(-1) - v_ref.reshape(-1)).abs().max()) < 3e-2, float((v.reshape(-1) - v_ref.reshape(-1)).abs().max())
+    # rank agreement of the top move on almost every board
+    agree = (p.argmax(1) == p_ref.argmax(1)).float().mean()
+    assert agree >= 0.8, float(agree)
+
+
+def test_engine_nhwc_planes_equal_nchw_planes():
+    eng_a = SelfPlayEngine(None, {"C": 2, "num_searches": 8}, 16, chess960=True, planes_dtype=torch.bfloat16)
+    eng_b = SelfPlayEngine(None, {"C": 2, "num_searches": 8}, 16, chess960=True, planes_dtype="nhwc128")
+    sch = list(range(100, 116))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for e in (eng_a, eng_b):
+        e.new_games(sch)
+        e.begin()
+    for step in range(8):
+        torch.cuda.synchronize()
+        a = eng_a.planes.float()
+        b = eng_b.planes.float()
+        assert torch.equal(b[:, :, 119:], torch.zeros_like(b[:, :, 119:]))
+        assert torch.equal(b[:, :, :119].transpose(1, 2).reshape(16, 119, 8, 8), a), "step %d" % step
+        policy = torch.softmax(torch.randn(16, N.SZ_ACTIONS, generator=g, device="cuda"), 1).contiguous()
+        value = torch.rand(16, generator=g, device="cuda") * 2 - 1
+        eng_a.step(policy, value)
+        eng_b.step(policy, value)
+    eng_a.close(); eng_b.close()

@@ -1,0 +1,35 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C, torch
+import sigma_zero_amd as sz
+from sigma_zero_amd import _native as N
+from sigma_zero_amd.fastnet import FastPolicyNet, _pack, planes_nchw_to_nhwc128
+from sigma_zero_amd.network import FLOPS_PER_BOARD
+
+def timeit(fn, n=20, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+
+for B in (512, 4096):
+    x = torch.randn(B, 64, 256, device="cuda").to(torch.bfloat16)
+    res = torch.randn(B, 64, 256, device="cuda").to(torch.bfloat16)
+    out = torch.empty_like(x)
+    w = _pack(torch.randn(256, 256, 3, 3) * 0.02, 256, 3, "cuda")
+    bias = torch.zeros(256, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def run(r=None):
+        N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()) if r else None, C.c_void_p(out.data_ptr()), B, 256, 3, 1, st)
+    dt = timeit(lambda: run()); fl = 2 * B * 64 * 256 * 2304
+    print("conv3x3 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
+    dt = timeit(lambda: run(True))
+    print("conv3x3+res B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    fast = FastPolicyNet(net)
+    planes = planes_nchw_to_nhwc128((torch.rand(B, 119, 8, 8, device="cuda") < 0.12).float())
+    dt = timeit(lambda: fast(planes, inference=True), n=10)
+    print("FastPolicyNet B=%d: %.2f ms  %.1f TFLOP/s  %.0f evals/s" % (B, dt * 1e3, B * FLOPS_PER_BOARD / dt / 1e12, B / dt))
+    dt = timeit(lambda: fast.tower(planes), n=10)
+    print("  tower only: %.2f ms" % (dt * 1e3))
