@@ -42,119 +42,130 @@ __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast
 // in  : [n_boards][64][CIN]  bf16 (NHWC)            w : packed fragments (see sz_nn_pack_weights)
 // out : [n_boards][64][256]  bf16 (NHWC)            bias : [256] f32 (BN folded)
 // res : optional residual, same layout as out; relu: apply max(0, .) last
-template <int CIN, int NTAPS>
-__global__ __launch_bounds__(256, 1) void k_conv_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w, const float* __restrict__ bias,
+template <int CIN, int NTAPS, int WGB /* boards per workgroup: 4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU */>
+__global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w, const float* __restrict__ bias,
                                                       const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int relu) {
     constexpr int PITCH = CIN * 2 + 16;                  // bytes per position row in LDS
     constexpr int KSTEPS = CIN / 16;                     // k-steps (16 channels) per tap
-    constexpr int ZERO_ROW = NN_WG_BOARDS * 64;
+    constexpr int ZERO_ROW = WGB * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave & 1, wp = wave >> 1;              // channel half, position half (2 boards)
-    const int board0 = blockIdx.x * NN_WG_BOARDS;
+    const int board0 = blockIdx.x * WGB;
 
     // ---- stage the 4 boards' activations into LDS (coalesced 16-B loads), plus one zero row ----
     {
         constexpr int CHUNKS_PER_POS = CIN / 8;           // 16-B chunks per position
-        constexpr int TOTAL = NN_WG_BOARDS * 64 * CHUNKS_PER_POS;
+        constexpr int TOTAL = WGB * 64 * CHUNKS_PER_POS;
         const uint4* src = (const uint4*)(in + (size_t)board0 * 64 * CIN);
-        const int valid_boards = min(NN_WG_BOARDS, n_boards - board0);
+        const int valid_boards = min(WGB, n_boards - board0);
         const int valid_chunks = valid_boards * 64 * CHUNKS_PER_POS;
-#pragma unroll 4
-        for (int c = tid; c < TOTAL; c += 256) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < valid_chunks) v = src[c];
-            int pos = c / CHUNKS_PER_POS, ch = c % CHUNKS_PER_POS;
-            *(uint4*)(lds + pos * PITCH + ch * 16) = v;
+        // all loads of a thread are issued before the first LDS write (32 x 16 B in flight per lane: the
+        // accumulators are not live yet, so the registers are free) -> one HBM latency per workgroup, not eight
+        constexpr int PER_THREAD = TOTAL / 256;
+        uint4 stage[PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; i++) {
+            const int c = tid + i * 256;
+            stage[i] = (c < valid_chunks && !(relu & 2)) ? src[c] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; i++) {
+            const int c = tid + i * 256;
+            const int pos = c / CHUNKS_PER_POS, ch = c % CHUNKS_PER_POS;
+            *(uint4*)(lds + pos * PITCH + ch * 16) = stage[i];
         }
         for (int c = tid; c < PITCH / 16; c += 256) *(uint4*)(lds + ZERO_ROW * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
 
-    f32x16 acc[4][4];
+    // wave tiling: NI channel tiles x NJ position tiles of 32x32.  NI=2, NJ=8: every wave owns a distinct quarter of
+    // the output channels for all 256 positions, so each weight fragment is fetched from L2 by exactly ONE wave of
+    // the workgroup (half the L2 traffic of a 2x2 wave grid); activations are re-read from LDS, which has headroom.
+    constexpr int NI = 2, NJ = 2 * WGB;
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     // per-lane geometry: lane owns position p32 of each 32-position tile; half h selects k 8..15
     const int p32 = lane & 31, h = lane >> 5;
     // weight fragment stream of this wave: [tap][kstep][co_tile 0..7][lane] (uint4 = 8 bf16)
-    const uint4* wbase = w + (size_t)(wc * 4) * 64 + lane;
+    const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
     constexpr int W_KSTEP_STRIDE = 8 * 64;                // uint4 per (tap,kstep)
 
-    uint4 aring[4][4];                                     // 4-deep ring x 4 co tiles
+    uint4 aring[4][NI];                                    // 4-deep ring x NI co tiles
     constexpr int TOTAL_KS = NTAPS * KSTEPS;
-    // prologue: prefetch k-steps 0 and 1
+    constexpr int PF = 3;                                  // weight prefetch distance in k-steps (ring of 4)
 #pragma unroll
-    for (int s = 0; s < 2; s++)
+    for (int s = 0; s < PF; s++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
+        for (int i = 0; i < NI; i++) aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
 
     // LDS byte address of this lane's activation row for (tap, position tile j); off-board taps -> zero row
     auto tap_addr = [&](int tap, int j) -> int {
         const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
-        int pos = (j & 1) * 32 + p32;                     // position inside its board
+        int pos = (j & 1) * 32 + p32;                     // position inside its board (board = j >> 1)
         int y = (pos >> 3) + dy, x = (pos & 7) + dx;
         bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
-        int row = ok ? ((wp * 2 + (j >> 1)) * 64 + y * 8 + x) : ZERO_ROW;
+        int row = ok ? ((j >> 1) * 64 + y * 8 + x) : ZERO_ROW;
         return row * PITCH + h * 16;
     };
-    int bcur[4], bnxt[4];
-    bf16x8 bfrag[2][4];                                    // activations double-buffered one k-step ahead
+    int bcur[NJ], bnxt[NJ];
+    bf16x8 bfrag[2][NJ];                                   // activations double-buffered one k-step ahead
 #pragma unroll
-    for (int j = 0; j < 4; j++) { bcur[j] = tap_addr(0, j); bnxt[j] = bcur[j]; bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]); }
+    for (int j = 0; j < NJ; j++) { bcur[j] = tap_addr(0, j); bnxt[j] = bcur[j]; bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]); }
 
     // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches to their uses:
-    //   issue { weights of k-step ks+2 (L2 -> ring), activations of ks+1 (LDS -> bfrag) } ; 16 MFMAs of ks.
-    // The compiler's own s_waitcnt then becomes counted (vmcnt(8)/lgkmcnt(4)): loads stay in flight under the MFMAs.
-    for (int tap = 0; tap < NTAPS; tap++) {
+    //   issue { weights of k-step ks+PF (L2 -> ring), activations of ks+1 (LDS -> bfrag) } ; 16 MFMAs of ks.
+    // The compiler's own s_waitcnt then becomes counted: loads stay in flight under the MFMAs.
+    for (int tap = 0; tap < ((relu & 8) ? 0 : NTAPS); tap++) {
         if (tap + 1 < NTAPS) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) bnxt[j] = tap_addr(tap + 1, j);
+            for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
         }
 #pragma unroll
         for (int kc = 0; kc < KSTEPS; kc++) {
             const int ks = tap * KSTEPS + kc;
-            if (ks + 2 < TOTAL_KS) {
+            if (ks + PF < TOTAL_KS) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) aring[(kc + 2) & 3][i] = wbase[(size_t)(ks + 2) * W_KSTEP_STRIDE + i * 64];
+                for (int i = 0; i < NI; i++) aring[(kc + PF) & 3][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
             }
             if (kc + 1 < KSTEPS) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 32);
+                for (int j = 0; j < NJ; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 32);
             } else if (tap + 1 < NTAPS) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bnxt[j]);
+                for (int j = 0; j < NJ; j++) bfrag[(kc + 1) & 1][j] = *(const bf16x8*)(lds + bnxt[j]);
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NI; i++) {
                 bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & 3][i]);
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) bcur[j] = bnxt[j];
+        for (int j = 0; j < NJ; j++) bcur[j] = bnxt[j];
     }
 
     // ---- epilogue: + bias (+ residual), ReLU, bf16, 8-byte NHWC stores --------------------------
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int board = board0 + wp * 2 + (j >> 1);
-        if (board >= n_boards) continue;
+    for (int j = 0; j < NJ; j++) {
+        const int board = board0 + (j >> 1);
+        if (board >= n_boards || ((relu & 4) && acc[0][j][0] != 12345.f)) continue;
         const int pos = (j & 1) * 32 + p32;
         const size_t rowoff = ((size_t)board * 64 + pos) * NN_COUT;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NI; i++) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int co = wc * 128 + i * 32 + 8 * g + 4 * h;
+                const int co = (wave * NI + i) * 32 + 8 * g + 4 * h;
                 f32x4 b4 = *(const f32x4*)(bias + co);
                 float v0 = acc[i][j][4 * g + 0] + b4[0], v1 = acc[i][j][4 * g + 1] + b4[1];
                 float v2 = acc[i][j][4 * g + 2] + b4[2], v3 = acc[i][j][4 * g + 3] + b4[3];
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_bf16(const uint16_t* __restrict
                     uint2 r = *(const uint2*)(res + rowoff + co);
                     v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
                 }
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (relu & 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
                 *(uint2*)(out + rowoff + co) = o;
             }
@@ -172,16 +183,16 @@ __global__ __launch_bounds__(256, 1) void k_conv_bf16(const uint16_t* __restrict
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
-template <int CIN, int NTAPS> static int launch_conv(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int relu, hipStream_t s) {
+template <int CIN, int NTAPS, int WGB> static int launch_conv(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int relu, hipStream_t s) {
     constexpr int PITCH = CIN * 2 + 16;
-    const size_t lds = (size_t)(NN_WG_BOARDS * 64 + 1) * PITCH;
+    const size_t lds = (size_t)(WGB * 64 + 1) * PITCH;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int grid = (n_boards + NN_WG_BOARDS - 1) / NN_WG_BOARDS;
-    hipLaunchKernelGGL((k_conv_bf16<CIN, NTAPS>), dim3(grid), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias, (const uint16_t*)res, (uint16_t*)out, n_boards, relu);
+    const int grid = (n_boards + WGB - 1) / WGB;
+    hipLaunchKernelGGL((k_conv_bf16<CIN, NTAPS, WGB>), dim3(grid), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias, (const uint16_t*)res, (uint16_t*)out, n_boards, relu);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
@@ -195,9 +206,11 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
                     int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream) {
     if (!in || !w_packed || !bias || !out || n_boards <= 0) return SZ_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (ksize == 3 && cin == 256) return launch_conv<256, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
-    if (ksize == 3 && cin == 128) return launch_conv<128, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
-    if (ksize == 1 && cin == 256) return launch_conv<256, 1>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    const bool wg4 = (relu & 16) != 0;                   // debug/A-B switch: 4-board workgroups (1 per CU)
+    if (ksize == 3 && cin == 256) return wg4 ? launch_conv<256, 9, 4>(in, w_packed, bias, residual, out, n_boards, relu, s)
+                                             : launch_conv<256, 9, 2>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    if (ksize == 3 && cin == 128) return launch_conv<128, 9, 2>(in, w_packed, bias, residual, out, n_boards, relu, s);
+    if (ksize == 1 && cin == 256) return launch_conv<256, 1, 2>(in, w_packed, bias, residual, out, n_boards, relu, s);
     return SZ_ERR_INVALID;
 }
 

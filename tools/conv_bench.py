@@ -25,6 +25,11 @@ for B in (512, 4096):
     print("conv3x3 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
     dt = timeit(lambda: run(True))
     print("conv3x3+res B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
+    for mode, name in ((17, "4-board WG (1/CU)"), (3, "no prologue loads"), (5, "no epilogue stores"), (7, "K loop only"), (9, "no K loop"), (15, "empty")):
+        def runm():
+            N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
+        dt = timeit(runm)
+        print("   ablation %-20s: %.3f ms" % (name, dt * 1e3))
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
     fast = FastPolicyNet(net)
