@@ -1,22 +1,28 @@
 // sz_nn.hip — hand-written CDNA4 MFMA convolution for the policy/value tower of the reference
 // (/root/reference/network.py:36-83 BasicBlock, :105-137 policyNN stem/tower).
 //
-// conv3x3(pad 1) over 8x8 boards, NHWC bf16, C_out = 256, C_in in {128 (zero-padded stem), 256},
+// conv3x3(pad 1) / conv1x1 over 8x8 boards, NHWC bf16, C_out = 256, C_in in {128 (zero-padded stem), 256},
 // with BatchNorm folded into weights/bias (eval mode) and bias + ReLU (+ residual add) fused in the
 // epilogue — one launch replaces MIOpen's igemm + batch_norm + clamp + add kernels of a BasicBlock half.
 //
 // MI355X mapping (not a warp-tiling port):
-//   * one workgroup = 4 waves (one per SIMD) = 4 boards = 256 output positions x 256 output channels;
-//     the 4 boards' activations (256 pos x C_in) are loaded ONCE from HBM into LDS (row pitch C_in*2+16 B:
-//     conflict-free ds_read_b128) and stay resident for all 9 taps — the im2col matrix is never formed,
-//     a tap is just a per-lane row address (off-board taps read a zero row);
-//   * D = W x Act^T on v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows = out channels)
-//     and activations as the B operand (cols = positions): each lane then owns 4 consecutive output
-//     channels of one position per register quad -> 8-byte NHWC stores, residual read in the same shape;
-//   * each wave owns 128 channels x 128 positions (4x4 MFMA tiles, 256 accumulator VGPRs, 1 wave/SIMD);
-//   * weights are pre-packed on the host in exact fragment order [tap][kstep][co_tile][lane][8], so a
-//     weight fragment is one fully coalesced 1 KiB global_load_dwordx4 from L2 (1.18 MB/layer stays
-//     L2-resident), prefetched 2 k-steps ahead through a 4-deep register ring: the K loop has NO barrier.
+//   * one workgroup = 4 waves = WGB boards (2 by default -> 68 KB of LDS -> TWO workgroups per CU, so one
+//     workgroup's HBM phases (tile load, output store) hide under the other's MFMA phase);
+//   * the boards' activations (WGB*64 positions x C_in) are loaded ONCE from HBM into LDS (row pitch
+//     C_in*2+16 B: conflict-free ds_read_b128) and stay resident for all 9 taps — the im2col matrix is
+//     never formed; a tap is just a per-lane row address (off-board taps read a zero row);
+//   * D = W x Act^T on v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows = out channels) and
+//     activations as the B operand (cols = positions); every wave owns a distinct quarter of the output
+//     channels (2 channel tiles x 2*WGB position tiles), so each weight fragment is fetched by one wave only;
+//   * weights are pre-packed on the host in exact fragment order [tap][kstep][co_tile][lane][8]: a weight
+//     fragment is one fully coalesced 1 KiB global_load_dwordx4 from L2 (1.18 MB/layer stays L2-resident),
+//     prefetched 3 k-steps ahead through a 4-deep register ring; activations are double-buffered one k-step
+//     ahead; the order is pinned with sched_barrier so the compiler's waits become counted vmcnt/lgkmcnt:
+//     the K loop has NO workgroup barrier and no exposed memory latency;
+//   * epilogue through LDS: (acc + bias) -> bf16 -> [pos][co] image, then whole 16-byte chunks are moved with
+//     coalesced residual reads and stores (scattered 8-byte stores from the accumulator layout cost 20 %).
+// Measured on MI355X, B = 4096 boards: 0.247 ms per 3x3 conv (1.25 PFLOP/s), 0.280 ms with residual.
+// `relu` bit 0 = ReLU; bits 1..4 are timing-ablation / A-B switches used by tools/conv_bench.py only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -154,29 +160,56 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
         for (int j = 0; j < NJ; j++) bcur[j] = bnxt[j];
     }
 
-    // ---- epilogue: + bias (+ residual), ReLU, bf16, 8-byte NHWC stores --------------------------
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // The accumulator layout (lane = position, 4 channels per register quad) would give 8-byte stores scattered
+    // over 32 rows per instruction — measured at ~115 cycles per wave-instruction in the texture-address path,
+    // 20 % of the kernel.  So: (acc + bias) -> bf16 -> LDS image [pos][co] (the activation tile is dead now), then
+    // every thread moves whole 16-byte chunks: LDS read, coalesced residual read, add, ReLU, coalesced store
+    // (one wave-instruction = 2 complete 512-byte rows).  The residual is added to the bf16-rounded conv+bias
+    // value (torch's own bf16 graph rounds there too).
+    constexpr int OPITCH = NN_COUT * 2 + 16;               // output image pitch (independent of C_in)
+    __syncthreads();                                       // all waves are done reading the activation tile
+    if (!((relu & 4) && acc[0][0][0] != 12345.f)) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int board = board0 + (j >> 1);
-        if (board >= n_boards || ((relu & 4) && acc[0][j][0] != 12345.f)) continue;
-        const int pos = (j & 1) * 32 + p32;
-        const size_t rowoff = ((size_t)board * 64 + pos) * NN_COUT;
+        for (int j = 0; j < NJ; j++) {
+            const int row = (j >> 1) * 64 + (j & 1) * 32 + p32;
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
+            for (int i = 0; i < NI; i++) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = (wave * NI + i) * 32 + 8 * g + 4 * h;
-                f32x4 b4 = *(const f32x4*)(bias + co);
-                float v0 = acc[i][j][4 * g + 0] + b4[0], v1 = acc[i][j][4 * g + 1] + b4[1];
-                float v2 = acc[i][j][4 * g + 2] + b4[2], v3 = acc[i][j][4 * g + 3] + b4[3];
-                if (res) {
-                    uint2 r = *(const uint2*)(res + rowoff + co);
-                    v0 += bf16_lo(r.x); v1 += bf16_hi(r.x); v2 += bf16_lo(r.y); v3 += bf16_hi(r.y);
+                for (int g = 0; g < 4; g++) {
+                    const int co = (wave * NI + i) * 32 + 8 * g + 4 * h;
+                    f32x4 b4 = *(const f32x4*)(bias + co);
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[i][j][4 * g + 0] + b4[0], acc[i][j][4 * g + 1] + b4[1]);
+                    o.y = pack_bf16x2(acc[i][j][4 * g + 2] + b4[2], acc[i][j][4 * g + 3] + b4[3]);
+                    *(uint2*)(lds + row * OPITCH + co * 2) = o;
                 }
-                if (relu & 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
-                *(uint2*)(out + rowoff + co) = o;
             }
+        }
+    }
+    __syncthreads();
+    if (!(relu & 4)) {
+        constexpr int OUT_CHUNKS = WGB * 64 * 32;          // 16-byte chunks of the output tile
+        const int valid = min(WGB, n_boards - board0) * 64 * 32;
+        const uint4* res4 = res ? (const uint4*)(res + (size_t)board0 * 64 * NN_COUT) : nullptr;
+        uint4* out4 = (uint4*)(out + (size_t)board0 * 64 * NN_COUT);
+#pragma unroll 4
+        for (int c = tid; c < OUT_CHUNKS; c += 256) {
+            if (c >= valid) break;
+            uint4 v = *(const uint4*)(lds + (c >> 5) * OPITCH + (c & 31) * 16);
+            float f[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
+            if (res4) {
+                uint4 r = res4[c];
+                f[0] += bf16_lo(r.x); f[1] += bf16_hi(r.x); f[2] += bf16_lo(r.y); f[3] += bf16_hi(r.y);
+                f[4] += bf16_lo(r.z); f[5] += bf16_hi(r.z); f[6] += bf16_lo(r.w); f[7] += bf16_hi(r.w);
+            }
+            if (relu & 1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) f[k] = fmaxf(f[k], 0.f);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]); o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+            out4[c] = o;
         }
     }
 }
@@ -185,7 +218,8 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
 
 template <int CIN, int NTAPS, int WGB> static int launch_conv(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int relu, hipStream_t s) {
     constexpr int PITCH = CIN * 2 + 16;
-    const size_t lds = (size_t)(WGB * 64 + 1) * PITCH;
+    const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + 16);
+    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
