@@ -202,15 +202,8 @@ def main():
     exps = st1["expansions"] - st0["expansions"]
     sum_depth = st1["sum_depth"] - st0["sum_depth"]
     sum_k = st1["sum_children"] - st0["sum_children"]
-    tot = torch.tensor([float(sims), float(exps), dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt_max = float(mx[2])
-    else:
-        dt_max = dt
-    total_sims, total_exps = float(tot[0]), float(tot[1])
+    from sigma_zero_amd.train_rl import aggregate_throughput
+    (total_sims, total_exps), dt_max = aggregate_throughput([sims, exps], dt, device=dev)
 
     if rank == 0:
         out = {

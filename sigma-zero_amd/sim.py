@@ -35,9 +35,12 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     import random
     model = model.to(device)
     if planes_dtype is None:
-        planes_dtype = next(model.parameters()).dtype
-        if planes_dtype not in (torch.float32, torch.bfloat16):
-            planes_dtype = torch.float32
+        if hasattr(model, "tower"):                       # FastPolicyNet: hand-written MFMA tower, NHWC planes
+            planes_dtype = "nhwc128"
+        else:
+            planes_dtype = next(model.parameters()).dtype
+            if planes_dtype not in (torch.float32, torch.bfloat16):
+                planes_dtype = torch.float32
     if c960 and scharnagl is None:
         scharnagl = [random.randint(0, 959) for _ in range(n_games)]
     if not c960:

