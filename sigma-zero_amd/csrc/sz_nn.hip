@@ -16,13 +16,14 @@
 //     channels (2 channel tiles x 2*WGB position tiles), so each weight fragment is fetched by one wave only;
 //   * weights are pre-packed on the host in exact fragment order [tap][kstep][co_tile][lane][8]: a weight
 //     fragment is one fully coalesced 1 KiB global_load_dwordx4 from L2 (1.18 MB/layer stays L2-resident),
-//     prefetched 3 k-steps ahead through a 4-deep register ring; activations are double-buffered one k-step
+//     prefetched 3 k-steps ahead through a 4-deep register ring (8-deep measured no faster); activations are double-buffered one k-step
 //     ahead; the order is pinned with sched_barrier so the compiler's waits become counted vmcnt/lgkmcnt:
 //     the K loop has NO workgroup barrier and no exposed memory latency;
 //   * epilogue through LDS: (acc + bias) -> bf16 -> [pos][co] image, then whole 16-byte chunks are moved with
 //     coalesced residual reads and stores (scattered 8-byte stores from the accumulator layout cost 20 %).
 // Measured on MI355X, B = 4096 boards: 0.247 ms per 3x3 conv (1.25 PFLOP/s), 0.280 ms with residual.
-// `relu` bit 0 = ReLU; bits 1..4 are timing-ablation / A-B switches used by tools/conv_bench.py only.
+// `relu` bit 0 = ReLU; higher bits are timing-ablation / A-B switches used by tools/conv_bench.py only
+// (2/4/8 skip load/store/K loop, 16 = 4-board workgroups, 32/64 + bits 8..15 = phase stagger, 0x10000 = no stagger).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,7 +51,7 @@ __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast
 // res : optional residual, same layout as out; relu: apply max(0, .) last
 template <int CIN, int NTAPS, int WGB /* boards per workgroup: 4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU */>
 __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w, const float* __restrict__ bias,
-                                                      const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int relu) {
+                                                      const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int relu, int n_cu) {
     constexpr int PITCH = CIN * 2 + 16;                  // bytes per position row in LDS
     constexpr int KSTEPS = CIN / 16;                     // k-steps (16 channels) per tap
     constexpr int ZERO_ROW = WGB * 64;
@@ -84,6 +85,23 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
     }
     __syncthreads();
 
+    // Phase stagger (speed only, never correctness): the two workgroups that share a CU are dispatched together
+    // and would run load / MFMA / store phases in lock-step, leaving the matrix pipe idle during both HBM phases.
+    // Delaying ONE of the first pair by about half a K loop keeps them out of phase for every later round.
+    if (WGB == 2) {
+        const int stagger = (relu >> 8) & 0xFF;            // sleep units (x ~8k cycles); 0 = off
+        if (stagger) {
+            bool second = false;
+            // measured: workgroups b and b + #CUs share a CU (round-robin dispatch); HW_ID.WAVE_ID bit 0 selects the
+            // same set.  A wrong guess only costs the sleep, never correctness.
+            if (relu & 32) second = ((int)blockIdx.x >= n_cu && (int)blockIdx.x < 2 * n_cu);
+            if (relu & 64) second = ((int)blockIdx.x < 2 * n_cu) && ((__builtin_amdgcn_s_getreg(0x1804) & 1) != 0);
+            second = __builtin_amdgcn_readfirstlane((int)second) != 0;
+            if (second)
+                for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+
     // wave tiling: NI channel tiles x NJ position tiles of 32x32.  NI=2, NJ=8: every wave owns a distinct quarter of
     // the output channels for all 256 positions, so each weight fragment is fetched from L2 by exactly ONE wave of
     // the workgroup (half the L2 traffic of a 2x2 wave grid); activations are re-read from LDS, which has headroom.
@@ -102,9 +120,10 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
     const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
     constexpr int W_KSTEP_STRIDE = 8 * 64;                // uint4 per (tap,kstep)
 
-    uint4 aring[4][NI];                                    // 4-deep ring x NI co tiles
+    constexpr int RING = 4;                                // weight ring depth (k-steps); 8 measured no faster
+    uint4 aring[RING][NI];
     constexpr int TOTAL_KS = NTAPS * KSTEPS;
-    constexpr int PF = 3;                                  // weight prefetch distance in k-steps (ring of 4)
+    constexpr int PF = RING - 1;                           // weight prefetch distance in k-steps
 #pragma unroll
     for (int s = 0; s < PF; s++)
 #pragma unroll
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
             const int ks = tap * KSTEPS + kc;
             if (ks + PF < TOTAL_KS) {
 #pragma unroll
-                for (int i = 0; i < NI; i++) aring[(kc + PF) & 3][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
+                for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
             }
             if (kc + 1 < KSTEPS) {
 #pragma unroll
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
-                bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & 3][i]);
+                bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                 for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
             }
@@ -221,12 +240,16 @@ template <int CIN, int NTAPS, int WGB> static int launch_conv(const void* in, co
     const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + 16);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     static bool attr_set = false;
+    static int n_cu = 256;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
         attr_set = true;
     }
+    if (WGB == 2 && !(relu & (32 | 64 | 0xFF00)) && !(relu & 0x10000)) relu |= 32 | (3 << 8);   // default: stagger the first co-resident pair
     const int grid = (n_boards + WGB - 1) / WGB;
-    hipLaunchKernelGGL((k_conv_bf16<CIN, NTAPS, WGB>), dim3(grid), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias, (const uint16_t*)res, (uint16_t*)out, n_boards, relu);
+    hipLaunchKernelGGL((k_conv_bf16<CIN, NTAPS, WGB>), dim3(grid), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias, (const uint16_t*)res, (uint16_t*)out, n_boards, relu, n_cu);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

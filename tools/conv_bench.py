@@ -25,6 +25,13 @@ for B in (512, 4096):
     print("conv3x3 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
     dt = timeit(lambda: run(True))
     print("conv3x3+res B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
+    for sel, sname in ((0x10000, "off"), (32, "b>=nCU"), (64, "hw wave id")):
+        for n in ((0,) if sel == 0x10000 else (1, 3)):
+            mode = 1 | sel | (n << 8)
+            def runs(r=None):
+                N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()) if r else None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
+            dt = timeit(lambda: runs()); dt2 = timeit(lambda: runs(True))
+            print("   stagger %-10s n=%d: %.3f ms  (+res %.3f ms)" % (sname, n, dt * 1e3, dt2 * 1e3))
     for mode, name in ((17, "4-board WG (1/CU)"), (3, "no prologue loads"), (5, "no epilogue stores"), (7, "K loop only"), (9, "no K loop"), (15, "empty")):
         def runm():
             N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
