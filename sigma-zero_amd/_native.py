@@ -45,6 +45,7 @@ EXPORTS = {
     "sz_debug_pending": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
     "sz_debug_position": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "sz_nn_conv_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
+    "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_error_string": (C.c_char_p, [C.c_int]),
     "sz_device_count": (C.c_int, []),

@@ -58,6 +58,7 @@ class FastPolicyNet:
         self.fc2_w = model.fc_v2.weight.detach().float().t().contiguous().to(dev)
         self.fc2_b = model.fc_v2.bias.detach().float().to(dev)
         self._bufs = {}
+        self.fuse_blocks = True      # one launch per BasicBlock (sz_nn_block_bf16); False = two sz_nn_conv_bf16 launches
         self.timing = None          # optional list: (start, end) HIP event pairs around every 3x3 C_in=256 conv launch
 
     def parameters(self):
@@ -73,7 +74,7 @@ class FastPolicyNet:
 
     def _conv(self, x, w, b, res, out, B, cin, ksize, relu=1):
         ev = None
-        if self.timing is not None and cin == 256 and ksize == 3:
+        if self.timing is not None and cin == 256 and ksize == 3 and not self.fuse_blocks:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         self._launch(x, w, b, res, out, B, cin, ksize, relu)
@@ -93,10 +94,25 @@ class FastPolicyNet:
         a, t, c = self._buffers(B)
         self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3)
         for (w1, b1, w2, b2) in self.blocks:
-            self._conv(a, w1, b1, None, t, B, 256, 3)
-            self._conv(t, w2, b2, a, c, B, 256, 3)
+            if self.fuse_blocks:
+                self._block(a, w1, b1, w2, b2, c, B)
+            else:
+                self._conv(a, w1, b1, None, t, B, 256, 3)
+                self._conv(t, w2, b2, a, c, B, 256, 3)
             a, c = c, a
         return a, t
+
+    def _block(self, x, w1, b1, w2, b2, out, B):
+        ev = None
+        if self.timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2.data_ptr()),
+                                         C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, 0,
+                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_block_bf16")
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
 
     @torch.no_grad()
     def __call__(self, planes, inference=True):

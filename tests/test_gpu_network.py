@@ -54,6 +54,31 @@ def test_conv_matches_torch_fp32(B, cin, ksize, use_res, relu, mode):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
+@pytest.mark.parametrize("B", [2, 5, 131])
+def test_fused_block_matches_torch_fp32(B):
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x = torch.randn(B, 256, 8, 8, generator=g, device="cuda").to(torch.bfloat16)
+    w1 = torch.randn(256, 256, 3, 3, generator=g, device="cuda") * (1.0 / 2304 ** 0.5)
+    w2 = torch.randn(256, 256, 3, 3, generator=g, device="cuda") * (1.0 / 2304 ** 0.5)
+    b1 = torch.randn(256, generator=g, device="cuda") * 0.3
+    b2 = torch.randn(256, generator=g, device="cuda") * 0.3
+    x_nhwc = x.reshape(B, 256, 64).transpose(1, 2).contiguous()
+    out = torch.empty(B, 64, 256, dtype=torch.bfloat16, device="cuda")
+    wp1, wp2 = _pack(w1, 256, 3, "cuda"), _pack(w2, 256, 3, "cuda")          # keep the packed tensors alive across the launch
+    N.check(N.lib().sz_nn_block_bf16(C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(wp1.data_ptr()), C.c_void_p(b1.data_ptr()),
+                                     C.c_void_p(wp2.data_ptr()), C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, 0,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    t = torch.relu(F.conv2d(x.float(), w1.to(torch.bfloat16).float(), b1, padding=1))
+    mid = F.conv2d(t.to(torch.bfloat16).float(), w2.to(torch.bfloat16).float(), b2, padding=1)     # t is stored as bf16 (in LDS)
+    ref = torch.relu(mid + x.float())
+    got = out.float().transpose(1, 2).reshape(B, 256, 8, 8)
+    # bf16 roundings: t (propagated through conv2: ~2^-8 * |t| * sqrt(K) * |w| ~ 2^-8), conv2+bias, output
+    tol = 2 ** -7 * ref.abs() + 2 ** -7 * mid.abs() + 2e-2
+    err = (got - ref).abs()
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
 def test_fast_network_matches_fp32_policynn():
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()

@@ -37,6 +37,11 @@ for B in (512, 4096):
             N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
         dt = timeit(runm)
         print("   ablation %-20s: %.3f ms" % (name, dt * 1e3))
+    w2 = _pack(torch.randn(256, 256, 3, 3) * 0.02, 256, 3, "cuda")
+    def runb():
+        N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, 0, st)
+    dt = timeit(runb)
+    print("fused block B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, 2 * fl / dt / 1e12))
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
     fast = FastPolicyNet(net)
