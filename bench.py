@@ -234,9 +234,11 @@ def main():
                        "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
                        "forward_ms": nn_ms, "useful_boards_per_forward": exps / launches}
             if fast and conv_events:
-                # dominant kernel of the whole job: k_conv_bf16<256,9> (38 of the 41 tower launches, >90 % of GPU time)
+                # dominant kernel of the whole job (>90 % of GPU time): k_block_bf16 = one fused BasicBlock (two 3x3 convs)
+                # per launch, or k_conv_bf16<256,9> when block fusion is off
                 conv_ms = float(np.mean([s.elapsed_time(e) for s, e in conv_events]))
-                conv_flop = 2.0 * B * 64 * 256 * 2304
+                fused = getattr(model, "fuse_blocks", False)
+                conv_flop = 2.0 * B * 64 * 256 * 2304 * (2 if fused else 1)
                 ctf = conv_flop / (conv_ms * 1e-3) / 1e12
                 traffic = None
                 try:
@@ -244,7 +246,8 @@ def main():
                         traffic = json.load(f)
                 except Exception:
                     pass
-                out["roofline"] = {"kernel": "k_conv_bf16<256,9> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
+                out["roofline"] = {"kernel": "k_block_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU)" if fused
+                                   else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
                                    "launch_ms": conv_ms, "algorithmic_flop_per_launch": conv_flop, "sampled_launches": len(conv_events),
                                    "traffic": traffic}

@@ -134,12 +134,17 @@ int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, 
  * in [n_boards,64,cin] (cin 128 or 256), out/residual [n_boards,64,256], bias [256] f32, w_packed from sz_nn_pack_weights. */
 int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
                     int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream);
+/* flag for `relu`/`flags` of the two entry points below: the weights were packed by sz_nn_pack_weights16 and the
+ * 16x16x32 MFMA kernels are used (same results; the chip holds a higher clock on that shape) */
+#define SZ_NN_W16 0x40000
 /* One whole BasicBlock (network.py:36-83) in one launch: out = relu(conv3x3(relu(conv3x3(in,w1)+b1),w2)+b2+in); the
  * intermediate activation stays in LDS.  in/out [n_boards,64,256] bf16 NHWC, out != in. */
 int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* out,
                      int32_t n_boards, int32_t flags, void* stream);
 /* host: torch conv weight [256,cin_real,k,k] f32 -> MFMA fragment order [k*k][cin_padded/16][8][64][8] bf16 */
 int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
+
+int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
 
 const char* sz_error_string(int code);
 int sz_device_count(void);

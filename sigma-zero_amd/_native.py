@@ -8,6 +8,7 @@ from . import build as _build
 SZ_RING, SZ_PLANES, SZ_ACTIONS, SZ_MAX_MOVES, SZ_POS_BYTES, SZ_MASK_WORDS = 256, 119, 4672, 218, 80, 73
 SZ_OK, SZ_ERR_INVALID, SZ_ERR_HIP, SZ_ERR_CAPACITY, SZ_ERR_NO_DEVICE, SZ_ERR_STATE, SZ_ERR_ZERO_VISITS = 0, -1, -2, -3, -4, -5, -6
 SZ_PLANES_F32, SZ_PLANES_BF16, SZ_PLANES_NHWC128_BF16 = 0, 1, 2
+SZ_NN_W16 = 0x40000
 
 
 class sz_config(C.Structure):
@@ -46,6 +47,7 @@ EXPORTS = {
     "sz_debug_position": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "sz_nn_conv_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
+    "sz_nn_pack_weights16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_error_string": (C.c_char_p, [C.c_int]),
     "sz_device_count": (C.c_int, []),

@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
 // ---- the K loop: acc[i][j] += W[tap,k] x Act[tap,k]^T over all taps and channels ----------------------------
 // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches to their uses:
 //   issue { weights of k-step ks+PF (L2 -> ring), activations of ks+1 (LDS -> bfrag) } ; NI*NJ MFMAs of ks.
-template <int CIN, int NTAPS, int WGB>
+template <int CIN, int NTAPS, int WGB, bool PROBE16 = false>
 __device__ __forceinline__ void conv_kloop(const unsigned char* lds, const uint4* __restrict__ w, f32x16 (&acc)[NN_NI][2 * WGB], bool skip) {
     constexpr int PITCH = CIN * 2 + 16;
     constexpr int KSTEPS = CIN / 16;
@@ -135,7 +135,19 @@ __device__ __forceinline__ void conv_kloop(const unsigned char* lds, const uint4
             for (int i = 0; i < NI; i++) {
                 bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; j++) {
+                    if constexpr (PROBE16) {
+                        // timing probe only (numerically meaningless): the same operands through twice as many 16x16x32 MFMAs
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            f32x4 c4 = {acc[i][j][8 * q], acc[i][j][8 * q + 1], acc[i][j][8 * q + 2], acc[i][j][8 * q + 3]};
+                            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], c4, 0, 0, 0);
+                            acc[i][j][8 * q] = c4[0]; acc[i][j][8 * q + 1] = c4[1]; acc[i][j][8 * q + 2] = c4[2]; acc[i][j][8 * q + 3] = c4[3];
+                        }
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -199,6 +211,109 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
     }
 }
 
+// =================================================================================================================
+// 16x16x32 MFMA path.  Same data movement and the same number of matrix-pipe cycles as the 32x32x16 path, but the chip
+// holds a ~15 % higher clock on this shape under bf16 load (measured with the timing probe in tools/conv_bench.py:
+// 0.212 vs 0.250 ms per conv at B = 4096; MI355X_MICROARCH.md "DVFS give-back" item 7).
+//   wave tile 64 channels x WGB*64 positions = 4 channel tiles(16) x 4*WGB position tiles(16), 4 acc regs each;
+//   one k-step = 32 channels; it is executed as two half-steps over the position halves (16 MFMAs = 256 cycles each):
+//   weights (4 fragments per k-step) ride a 2-deep ring one k-step ahead, activations are double-buffered one
+//   half-step ahead.  Weight order: [tap][k32][co_tile16][lane][8] (sz_nn_pack_weights16).
+// =================================================================================================================
+template <int CIN, int NTAPS, int WGB>
+__device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip) {
+    constexpr int PITCH = CIN * 2 + 16;
+    constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
+    constexpr int ZERO_ROW = WGB * 64;
+    constexpr int NI = 4, NJ = 4 * WGB, NH = NJ / 2;       // channel tiles, position tiles, position tiles per half-step
+    constexpr int TOTAL_KS = NTAPS * KSTEPS;
+    constexpr int W_KSTEP_STRIDE = 16 * 64;                // uint4 per (tap,k32)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
+    const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 aring[2][NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) aring[0][i] = wbase[i * 64];
+    auto tap_addr = [&](int tap, int j) -> int {
+        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
+        int pos = (j & 3) * 16 + p16;                      // position inside its board (board = j >> 2)
+        int y = (pos >> 3) + dy, x = (pos & 7) + dx;
+        bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
+        int row = ok ? ((j >> 2) * 64 + y * 8 + x) : ZERO_ROW;
+        return row * PITCH + kg * 16;
+    };
+    int bcur[NJ], bnxt[NJ];
+    bf16x8 bfrag[2][NH];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { bcur[j] = tap_addr(0, j); bnxt[j] = bcur[j]; }
+#pragma unroll
+    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
+    for (int tap = 0; tap < (skip ? 0 : NTAPS); tap++) {
+        if (tap + 1 < NTAPS) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KSTEPS; kc++) {
+            const int ks = tap * KSTEPS + kc;
+#pragma unroll
+            for (int hs = 0; hs < 2; hs++) {
+                if (hs == 0 && ks + 1 < TOTAL_KS) {         // weights of the next k-step (slot freed by the previous half-step)
+#pragma unroll
+                    for (int i = 0; i < NI; i++) aring[(kc + 1) & 1][i] = wbase[(size_t)(ks + 1) * W_KSTEP_STRIDE + i * 64];
+                }
+                // activations of the next half-step
+                if (hs == 0) {
+#pragma unroll
+                    for (int j = 0; j < NH; j++) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
+                } else if (kc + 1 < KSTEPS) {
+#pragma unroll
+                    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
+                } else if (tap + 1 < NTAPS) {
+#pragma unroll
+                    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bnxt[j]);
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & 1][i]);
+#pragma unroll
+                    for (int j = 0; j < NH; j++)
+                        acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], acc[i][hs * NH + j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) bcur[j] = bnxt[j];
+    }
+}
+
+template <int WGB>
+__device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias, bool relu) {
+    constexpr int OPITCH = NN_COUT * 2 + 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4 * WGB; j++) {
+        const int row = (j >> 2) * 64 + (j & 3) * 16 + p16;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int co = (wave * 4 + i) * 16 + 4 * kg;    // C layout: col = lane&15 (position), row = 4*(lane>>4) + reg (channel)
+            f32x4 b4 = *(const f32x4*)(bias + co);
+            float v0 = acc[i][j][0] + b4[0], v1 = acc[i][j][1] + b4[1], v2 = acc[i][j][2] + b4[2], v3 = acc[i][j][3] + b4[3];
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+            *(uint2*)(lds + row * OPITCH + co * 2) = o;
+        }
+    }
+}
+
 // Phase stagger (speed only, never correctness): the two workgroups that share a CU are dispatched together and
 // would run load / MFMA / store phases in lock-step.  Measured: workgroups b and b + #CUs share a CU (round-robin
 // dispatch); HW_ID.WAVE_ID bit 0 selects the same set.  Delaying one of the first pair keeps later rounds out of phase.
@@ -223,7 +338,8 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv_bf16(const uin
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x16 acc[NN_NI][2 * WGB];
-    conv_kloop<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0);
+    if (CIN == 256 && NTAPS == 9 && WGB == 2 && (flags & 0x20000)) conv_kloop<CIN, NTAPS, WGB, true>(lds, w, acc, (flags & 8) != 0);
+    else conv_kloop<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0);
     __syncthreads();                                       // all waves are done reading the activation tile
     if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds<WGB>(lds, acc, bias, false);
     __syncthreads();
@@ -252,6 +368,43 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_block_bf16(const ui
     acc_to_lds<WGB>(lds, acc, b2, false);
     __syncthreads();
     lds_to_out<WGB>(lds, in, out, board0, n_boards, true); // + x (re-read, still L2/MALL-resident), ReLU
+}
+
+template <int CIN, int NTAPS, int WGB>
+__global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w, const float* __restrict__ bias,
+                                                        const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int flags, int n_cu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int board0 = blockIdx.x * WGB;
+    stage_tile<CIN, WGB>(lds, in, board0, n_boards, (flags & 2) != 0);
+    __syncthreads();
+    if (WGB == 2) phase_stagger(flags, n_cu);
+    f32x4 acc[4][4 * WGB];
+    conv_kloop16<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0);
+    __syncthreads();
+    if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds16<WGB>(lds, acc, bias, false);
+    __syncthreads();
+    if (!(flags & 4)) lds_to_out<WGB>(lds, res, out, board0, n_boards, (flags & 1) != 0);
+}
+
+template <int WGB>
+__global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_block16_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w1, const float* __restrict__ b1,
+                                                         const uint4* __restrict__ w2, const float* __restrict__ b2, uint16_t* __restrict__ out,
+                                                         int n_boards, int flags, int n_cu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int board0 = blockIdx.x * WGB;
+    stage_tile<256, WGB>(lds, in, board0, n_boards, false);
+    __syncthreads();
+    if (WGB == 2) phase_stagger(flags, n_cu);
+    f32x4 acc[4][4 * WGB];
+    conv_kloop16<256, 9, WGB>(lds, w1, acc, false);
+    __syncthreads();
+    acc_to_lds16<WGB>(lds, acc, b1, true);
+    __syncthreads();
+    conv_kloop16<256, 9, WGB>(lds, w2, acc, false);
+    __syncthreads();
+    acc_to_lds16<WGB>(lds, acc, b2, false);
+    __syncthreads();
+    lds_to_out<WGB>(lds, in, out, board0, n_boards, true);
 }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
@@ -300,6 +453,34 @@ template <int WGB> static int launch_block(const void* in, const void* w1, const
     return SZ_OK;
 }
 
+template <int CIN, int NTAPS> static int launch_conv16(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int flags, hipStream_t s) {
+    constexpr int WGB = 2, PITCH = CIN * 2 + 16;
+    const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + 16);
+    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv16_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv16_bf16<CIN, NTAPS, WGB>), dim3((n_boards + WGB - 1) / WGB), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w, bias,
+                       (const uint16_t*)res, (uint16_t*)out, n_boards, default_flags(flags, WGB), device_cus());
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
+    constexpr int WGB = 2;
+    const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_block16_bf16<WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_block16_bf16<WGB>), dim3((n_boards + WGB - 1) / WGB), dim3(256), lds, s, (const uint16_t*)in, (const uint4*)w1, b1, (const uint4*)w2, b2,
+                       (uint16_t*)out, n_boards, default_flags(flags, WGB), device_cus());
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
 extern "C" {
 
 // Fused conv (+folded BN) + bias (+ residual) (+ ReLU), NHWC bf16, C_out = 256.
@@ -309,6 +490,12 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
                     int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream) {
     if (!in || !w_packed || !bias || !out || n_boards <= 0) return SZ_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if (relu & SZ_NN_W16) {                                // weights packed for the 16x16x32 path (sz_nn_pack_weights16)
+        if (ksize == 3 && cin == 256) return launch_conv16<256, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
+        if (ksize == 3 && cin == 128) return launch_conv16<128, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
+        if (ksize == 1 && cin == 256) return launch_conv16<256, 1>(in, w_packed, bias, residual, out, n_boards, relu, s);
+        return SZ_ERR_INVALID;
+    }
     const bool wg4 = (relu & 16) != 0;                   // A/B switch: 4-board workgroups (1 per CU)
     if (ksize == 3 && cin == 256) return wg4 ? launch_conv<256, 9, 4>(in, w_packed, bias, residual, out, n_boards, relu, s)
                                              : launch_conv<256, 9, 2>(in, w_packed, bias, residual, out, n_boards, relu, s);
@@ -322,7 +509,27 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
 int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* out,
                      int32_t n_boards, int32_t flags, void* stream) {
     if (!in || !w1_packed || !bias1 || !w2_packed || !bias2 || !out || in == out || n_boards <= 0) return SZ_ERR_INVALID;
+    if (flags & SZ_NN_W16) return launch_block16(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
     return launch_block<2>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
+}
+
+// Weight packing for the 16x16x32 path: [taps][cin/32 k-steps][16 co tiles][64 lanes][8] bf16;
+//   lane l, elem j <- w[co = tile*16 + (l&15)][ci = kstep*32 + 8*(l>>4) + j]
+int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out) {
+    if (!w_in || !out || (ksize != 1 && ksize != 3) || cin_padded % 32 || cin_real > cin_padded) return SZ_ERR_INVALID;
+    const int taps = ksize * ksize, ksteps = cin_padded / 32;
+    for (int t = 0; t < taps; t++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int tile = 0; tile < 16; tile++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
+                        float v = (ci < cin_real) ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
+                        uint32_t u; memcpy(&u, &v, 4);
+                        uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+                        out[((((size_t)t * ksteps + ks) * 16 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
+                    }
+    return SZ_OK;
 }
 
 // Host-side weight packing into MFMA A-fragment order.

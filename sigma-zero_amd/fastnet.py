@@ -22,31 +22,38 @@ def _fold_bn(conv_w, bn, conv_b=None):
     return w.float(), b.float()
 
 
-def _pack(w, cin_padded, ksize, device):
-    """[256, cin, k, k] f32 -> MFMA A-fragment order (uint16 bf16 bits) on `device`."""
+def _pack(w, cin_padded, ksize, device, w16=False):
+    """[256, cin, k, k] f32 -> MFMA A-fragment order (uint16 bf16 bits) on `device`.
+    w16: fragment order of the 16x16x32 kernels (sz_nn_pack_weights16) instead of the 32x32x16 ones."""
     w = w.contiguous().cpu().float().numpy()
     co, cin = w.shape[0], w.shape[1]
     assert co == 256
-    out = np.zeros(ksize * ksize * (cin_padded // 16) * 8 * 64 * 8, dtype=np.uint16)
-    N.check(N.lib().sz_nn_pack_weights(w.ctypes.data_as(C.c_void_p), cin, cin_padded, ksize, out.ctypes.data_as(C.c_void_p)), "sz_nn_pack_weights")
+    out = np.zeros(ksize * ksize * cin_padded * 256, dtype=np.uint16)
+    fn = N.lib().sz_nn_pack_weights16 if w16 else N.lib().sz_nn_pack_weights
+    N.check(fn(w.ctypes.data_as(C.c_void_p), cin, cin_padded, ksize, out.ctypes.data_as(C.c_void_p)), "sz_nn_pack_weights")
     return torch.from_numpy(out.view(np.int16)).to(device)
 
 
 class FastPolicyNet:
-    def __init__(self, model, device="cuda:0"):
+    def __init__(self, model, device="cuda:0", mfma16=True):
         model = model.eval()
         self.device = torch.device(device)
         dev = self.device
+        self.w16 = bool(mfma16)              # 16x16x32 MFMA kernels (higher sustained clock) vs 32x32x16
+        self.flag = N.SZ_NN_W16 if self.w16 else 0
+        pack_fn = _pack
+        def _pack_w(w, cin_padded, ksize, device):
+            return pack_fn(w, cin_padded, ksize, device, w16=self.w16)
         self.layers = []          # (packed_w, bias, cin, ksize)
         w, b = _fold_bn(model.conv1.weight, model.norm_layer)
-        self.stem = (_pack(w, 128, 3, dev), b.to(dev).contiguous())
+        self.stem = (_pack_w(w, 128, 3, dev), b.to(dev).contiguous())
         self.blocks = []
         for blk in model.resnet_blocks:
             w1, b1 = _fold_bn(blk.conv1.weight, blk.bn1)
             w2, b2 = _fold_bn(blk.conv2.weight, blk.bn2)
-            self.blocks.append((_pack(w1, 256, 3, dev), b1.to(dev).contiguous(), _pack(w2, 256, 3, dev), b2.to(dev).contiguous()))
+            self.blocks.append((_pack_w(w1, 256, 3, dev), b1.to(dev).contiguous(), _pack_w(w2, 256, 3, dev), b2.to(dev).contiguous()))
         wp, bp = _fold_bn(model.conv_p1.weight, model.p_norm1)
-        self.p1 = (_pack(wp, 256, 1, dev), bp.to(dev).contiguous())
+        self.p1 = (_pack_w(wp, 256, 1, dev), bp.to(dev).contiguous())
         # heads (tiny): policy 1x1 256->73 (+bias), value 1x1 256->1 + BN + ReLU + MLP
         self.wp2 = model.conv_p2.weight.detach().view(73, 256).t().contiguous().to(dev).to(torch.bfloat16)      # [256,73]
         self.bp2 = model.conv_p2.bias.detach().float().to(dev)
@@ -85,7 +92,7 @@ class FastPolicyNet:
     def _launch(self, x, w, b, res, out, B, cin, ksize, relu):
         N.check(N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
                                         C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(out.data_ptr()),
-                                        B, cin, ksize, relu, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_conv_bf16")
+                                        B, cin, ksize, relu | self.flag, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_conv_bf16")
 
     @torch.no_grad()
     def tower(self, planes):
@@ -108,7 +115,7 @@ class FastPolicyNet:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         N.check(N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2.data_ptr()),
-                                         C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, 0,
+                                         C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, self.flag,
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_block_bf16")
         if ev is not None:
             ev[1].record()

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def _run_conv(x_nhwc, w, bias, res, cin_padded, ksize, relu, mode=0):
     B = x_nhwc.shape[0]
     out = torch.empty(B, 64, 256, dtype=torch.bfloat16, device="cuda")
-    wp = _pack(w, cin_padded, ksize, "cuda")
+    wp = _pack(w, cin_padded, ksize, "cuda", w16=bool(mode & N.SZ_NN_W16))
     N.check(N.lib().sz_nn_conv_bf16(C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bias.data_ptr()),
                                     C.c_void_p(res.data_ptr()) if res is not None else None, C.c_void_p(out.data_ptr()),
                                     B, cin_padded, ksize, int(relu) | mode, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -26,7 +26,7 @@ def _run_conv(x_nhwc, w, bias, res, cin_padded, ksize, relu, mode=0):
     return out
 
 
-@pytest.mark.parametrize("mode", [0, 16], ids=["wg2", "wg4"])
+@pytest.mark.parametrize("mode", [0, 16, N.SZ_NN_W16], ids=["wg2", "wg4", "mfma16"])
 @pytest.mark.parametrize("B,cin,ksize,use_res,relu", [(4, 256, 3, False, True), (7, 256, 3, True, True), (3, 119, 3, False, True),
                                                        (5, 256, 1, False, True), (8, 256, 3, True, False), (130, 256, 3, True, True),
                                                        (1031, 256, 3, True, True)])
@@ -54,8 +54,9 @@ def test_conv_matches_torch_fp32(B, cin, ksize, use_res, relu, mode):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
+@pytest.mark.parametrize("w16", [False, True], ids=["mfma32", "mfma16"])
 @pytest.mark.parametrize("B", [2, 5, 131])
-def test_fused_block_matches_torch_fp32(B):
+def test_fused_block_matches_torch_fp32(B, w16):
     g = torch.Generator(device="cuda").manual_seed(B)
     x = torch.randn(B, 256, 8, 8, generator=g, device="cuda").to(torch.bfloat16)
     w1 = torch.randn(256, 256, 3, 3, generator=g, device="cuda") * (1.0 / 2304 ** 0.5)
@@ -64,9 +65,9 @@ def test_fused_block_matches_torch_fp32(B):
     b2 = torch.randn(256, generator=g, device="cuda") * 0.3
     x_nhwc = x.reshape(B, 256, 64).transpose(1, 2).contiguous()
     out = torch.empty(B, 64, 256, dtype=torch.bfloat16, device="cuda")
-    wp1, wp2 = _pack(w1, 256, 3, "cuda"), _pack(w2, 256, 3, "cuda")          # keep the packed tensors alive across the launch
+    wp1, wp2 = _pack(w1, 256, 3, "cuda", w16=w16), _pack(w2, 256, 3, "cuda", w16=w16)   # keep the packed tensors alive across the launch
     N.check(N.lib().sz_nn_block_bf16(C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(wp1.data_ptr()), C.c_void_p(b1.data_ptr()),
-                                     C.c_void_p(wp2.data_ptr()), C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, 0,
+                                     C.c_void_p(wp2.data_ptr()), C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), B, N.SZ_NN_W16 if w16 else 0,
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     t = torch.relu(F.conv2d(x.float(), w1.to(torch.bfloat16).float(), b1, padding=1))
@@ -79,7 +80,8 @@ def test_fused_block_matches_torch_fp32(B):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
-def test_fast_network_matches_fp32_policynn():
+@pytest.mark.parametrize("mfma16", [False, True], ids=["mfma32", "mfma16"])
+def test_fast_network_matches_fp32_policynn(mfma16):
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
     # give BatchNorm non-trivial running statistics so that the folding is exercised
@@ -90,7 +92,7 @@ def test_fast_network_matches_fp32_policynn():
             m.running_var.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
             m.weight.data.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g, device="cuda") * 0.1)
-    fast = FastPolicyNet(net)
+    fast = FastPolicyNet(net, mfma16=mfma16)
     x = (torch.rand(37, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
     with torch.no_grad():
         p_ref, v_ref = net(x, inference=True)

@@ -288,3 +288,23 @@ def test_train_cycle_smoke_on_gpu():
     hist, games = train_rl.run_cycle(net, opt, sched, {"C": 2, "num_searches": 4, "max_plies": 12}, n_games=16, chess960=True, batch_size=8, total_steps=0)
     assert len(hist) >= 1 and all(np.isfinite(h).all() for h in hist)
     assert not torch.equal(sd_before, net.conv1.weight.detach())
+
+
+def test_capacity_overflow_is_reported_not_silent():
+    """a board that runs out of child slots raises SZ_ERR_CAPACITY through the stats path (sticky per-board flag)"""
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": 64}, 4, edges_per_board=230)
+    eng.new_games([-1] * 4)
+    ev = random_evaluator(1)
+    eng.begin()
+    for step in range(64):
+        p, v = ev(eng.planes, step)
+        eng.step(p, v)
+    with pytest.raises(N.NativeError) as ei:
+        eng.check_errors()
+    assert ei.value.code == N.SZ_ERR_CAPACITY
+    eng.close()
+
+
+def test_engine_refuses_without_model_device():
+    with pytest.raises(TypeError):
+        sz.MCTS0(game=object(), args={"C": 2, "num_searches": 4}, model=sz.policyNN({})).search(None)

@@ -25,7 +25,13 @@ for B in (512, 4096):
     print("conv3x3 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
     dt = timeit(lambda: run(True))
     print("conv3x3+res B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, fl / dt / 1e12))
-    for sel, sname in ((0x10000, "off"), (32, "b>=nCU"), (64, "hw wave id")):
+    for rep in range(3):
+        for mode, name in ((1, "32x32x16 (real)"), (1 | 0x20000, "16x16x32 probe")):
+            def runp():
+                N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
+            dt = timeit(runp, n=30)
+            print("   shape %-18s: %.3f ms" % (name, dt * 1e3))
+    for sel, sname in ((0x10000, "off"),):
         for n in ((0,) if sel == 0x10000 else (1, 3)):
             mode = 1 | sel | (n << 8)
             def runs(r=None):
@@ -37,6 +43,17 @@ for B in (512, 4096):
             N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, C.c_void_p(out.data_ptr()), B, 256, 3, mode, st)
         dt = timeit(runm)
         print("   ablation %-20s: %.3f ms" % (name, dt * 1e3))
+    w16a = _pack(torch.randn(256, 256, 3, 3) * 0.02, 256, 3, "cuda", w16=True)
+    for rep in range(2):
+        for r in (None, True):
+            def run16():
+                N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()) if r else None, C.c_void_p(out.data_ptr()), B, 256, 3, 1 | N.SZ_NN_W16, st)
+            dt = timeit(run16, n=30)
+            print("conv3x3 mfma16%s B=%d: %.3f ms  %.1f TFLOP/s" % ("+res" if r else "", B, dt * 1e3, fl / dt / 1e12))
+    def runb16():
+        N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, N.SZ_NN_W16, st)
+    dt = timeit(runb16)
+    print("fused block mfma16 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, 2 * fl / dt / 1e12))
     w2 = _pack(torch.randn(256, 256, 3, 3) * 0.02, 256, 3, "cuda")
     def runb():
         N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, 0, st)
@@ -44,9 +61,12 @@ for B in (512, 4096):
     print("fused block B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, 2 * fl / dt / 1e12))
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
+    fast32 = FastPolicyNet(net, mfma16=False)
     fast = FastPolicyNet(net)
     planes = planes_nchw_to_nhwc128((torch.rand(B, 119, 8, 8, device="cuda") < 0.12).float())
     dt = timeit(lambda: fast(planes, inference=True), n=10)
     print("FastPolicyNet B=%d: %.2f ms  %.1f TFLOP/s  %.0f evals/s" % (B, dt * 1e3, B * FLOPS_PER_BOARD / dt / 1e12, B / dt))
+    dt = timeit(lambda: fast32(planes, inference=True), n=10)
+    print("FastPolicyNet(mfma32) B=%d: %.2f ms  %.1f TFLOP/s  %.0f evals/s" % (B, dt * 1e3, B * FLOPS_PER_BOARD / dt / 1e12, B / dt))
     dt = timeit(lambda: fast.tower(planes), n=10)
     print("  tower only: %.2f ms" % (dt * 1e3))
