@@ -222,11 +222,18 @@ def main():
             tree_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_tree]))
             nn_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_nn]))
             launches = len(ev_tree)
-            plane_bytes = 2 if dtype == torch.bfloat16 else 4
+            # network-input bytes per board: NCHW 119x64 elements, or the NHWC image of 64 x 128 bf16 on the fast path
+            plane_bytes = (128.0 * 2 / 119) if fast else (2 if dtype == torch.bfloat16 else 4)
             bytes_per_launch = tree_bytes_per_launch(B, sims, exps, sum_depth, sum_k, plane_bytes) / launches
             ach = bytes_per_launch / (tree_ms * 1e-3) / 1e9
+            tree_traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_tree_latest.json")) as f:
+                    tree_traffic = json.load(f)
+            except Exception:
+                pass
             tree_roof = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": tree_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": tree_traffic, "launch_ms": tree_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step_time": tree_ms / (tree_ms + nn_ms)}
             fl = exps / launches * sz.network.FLOPS_PER_BOARD
             tf = fl / (nn_ms * 1e-3) / 1e12
