@@ -25,6 +25,8 @@ FENS = [
     "8/P7/8/8/8/8/7k/K7 w - - 0 1",                   # promotions (queen + under-promotions)
     "4k3/8/8/8/8/8/8/4K2R w K - 0 1",                 # castling with few pieces
     "8/8/5k2/8/8/3KR3/8/8 w - - 140 100",             # 75-move rule inside the tree
+    "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1",   # 218 legal moves: the maximum child span
+    "rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq f6 0 3",   # en passant available at the root
 ]
 
 
@@ -308,3 +310,33 @@ def test_capacity_overflow_is_reported_not_silent():
 def test_engine_refuses_without_model_device():
     with pytest.raises(TypeError):
         sz.MCTS0(game=object(), args={"C": 2, "num_searches": 4}, model=sz.policyNN({})).search(None)
+
+
+def test_inactive_and_ragged_boards():
+    """boards can be switched off (empty slots of a ragged batch): they never ask for an evaluation and keep their state"""
+    boards = make_boards(6, seed=2)
+    S = 10
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, 6)
+    for b, m in enumerate(boards):
+        eng.upload_game(b, m.ct)
+    active = [1, 0, 1, 1, 0, 1]
+    eng.set_active(active)
+    ev = random_evaluator(9)
+    eng.begin()
+    for step in range(S):
+        torch.cuda.synchronize()
+        _, _, _, _, status = eng.debug_pending()
+        for b in range(6):
+            assert bool(status[b] & 2) == bool(active[b]) or (status[b] & 4), (step, b)
+        p, v = ev(eng.planes, step)
+        eng.step(p, v)
+    eng.check_errors()
+    action, visits, n_child, _, _ = eng.root_children()
+    for b in range(6):
+        assert (n_child[b] > 0) == bool(active[b])
+        if active[b]:
+            assert visits[b, :n_child[b]].sum() == S - 1          # root.visit_count = 1 + S, first simulation expands the root
+    eng.play(np.full(6, 0.5))
+    rec = eng.fetch_ply()
+    assert rec["active"].tolist() == active
+    eng.close()

@@ -155,3 +155,44 @@ def test_fen_positions_match_oracle(fen):
         k = rng.randrange(len(idx))
         ct.push_action(idx[k])
         oct_.move_piece(moves[k])
+
+
+def test_dropin_module_names_resolve():
+    """the reference's own import lines (train_RL.py:2-6, eval.py, play.py) work against dropin/"""
+    import importlib, os, sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin")
+    sys.path.insert(0, d)
+    try:
+        for name in ("chess", "network", "chess_tensor", "mctsnode", "mcts", "sim"):
+            sys.modules.pop(name, None)
+        net = importlib.import_module("network")
+        ct = importlib.import_module("chess_tensor")
+        chess = importlib.import_module("chess")
+        assert importlib.import_module("sim").generate_training_data and importlib.import_module("mcts").MCTS0
+        assert net.policyNN is sz.policyNN and ct.ChessTensor is sz.ChessTensor
+        mask, qp = ct.actionsToTensor([chess.Move.from_uci("e2e4"), chess.Move.from_uci("a7a8q")], chess.WHITE)
+        assert mask.nonzero().flatten().tolist() == [8, 116] and qp == {"a7a8q": True}
+        assert [m.uci() for m in ct.tensorToAction(mask, chess.WHITE, qp)] == ["a7a8q", "e2e4"]
+    finally:
+        sys.path.remove(d)
+        for name in ("chess", "network", "chess_tensor", "mctsnode", "mcts", "sim"):
+            sys.modules.pop(name, None)
+
+
+def test_maximum_fanout_position():
+    """218 legal moves — the known maximum; the engine's child span (SZ_MAX_MOVES) is sized for it"""
+    fen = "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1"
+    ct = sz.ChessTensor(fen=fen)
+    oct_ = O.ChessTensor.from_fen(fen)
+    assert len(ct.legal_action_indices()) == 218 == len(oct_.legal_action_indices()[0])
+    assert ct.legal_action_indices() == oct_.legal_action_indices()[0]
+
+
+def test_promotion_and_en_passant_edge_cases():
+    for fen in ("8/P6k/8/8/8/8/p6K/8 w - - 0 1", "8/P6k/8/8/8/8/p6K/8 b - - 0 1",
+                "rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq f6 0 3",      # two ep candidates listed, one legal square
+                "8/8/8/8/k2Pp2Q/8/8/3K4 b - d3 0 1",                                    # ep capture would expose the king: illegal
+                "8/8/3p4/KPp4r/1R3p1k/8/4P1P1/8 w - c6 0 2"):                          # perft-3 classic: ep pin on the rank
+        ct = sz.ChessTensor(fen=fen)
+        oct_ = O.ChessTensor.from_fen(fen)
+        assert _compare_state(ct, oct_, fen) is False
