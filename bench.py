@@ -226,14 +226,15 @@ def main():
             plane_bytes = (128.0 * 2 / 119) if fast else (2 if dtype == torch.bfloat16 else 4)
             bytes_per_launch = tree_bytes_per_launch(B, sims, exps, sum_depth, sum_k, plane_bytes) / launches
             ach = bytes_per_launch / (tree_ms * 1e-3) / 1e9
-            tree_traffic = None
+            tree_traffic, tree_src = None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_tree_latest.json")) as f:
-                    tree_traffic = json.load(f)
+                    tree_src = json.load(f)
+                tree_traffic = tree_src["hbm_bytes_per_launch"] if (fast and B == 4096) else None
             except Exception:
                 pass
             tree_roof = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": tree_traffic, "launch_ms": tree_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": tree_traffic, "traffic_source": tree_src, "launch_ms": tree_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step_time": tree_ms / (tree_ms + nn_ms)}
             fl = exps / launches * sz.network.FLOPS_PER_BOARD
             tf = fl / (nn_ms * 1e-3) / 1e12
@@ -247,17 +248,18 @@ def main():
                 fused = getattr(model, "fuse_blocks", False)
                 conv_flop = 2.0 * B * 64 * 256 * 2304 * (2 if fused else 1)
                 ctf = conv_flop / (conv_ms * 1e-3) / 1e12
-                traffic = None
+                traffic, traffic_src = None, None          # HBM bytes per launch from committed rocprofv3 --pmc passes
                 try:
                     with open(os.path.join(ROOT, "profiles", "pmc_conv_latest.json")) as f:
-                        traffic = json.load(f)
+                        traffic_src = json.load(f)
+                    traffic = traffic_src["hbm_bytes_per_launch"] if fused else None
                 except Exception:
                     pass
                 out["roofline"] = {"kernel": "k_block_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU)" if fused
                                    else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
                                    "launch_ms": conv_ms, "algorithmic_flop_per_launch": conv_flop, "sampled_launches": len(conv_events),
-                                   "traffic": traffic}
+                                   "traffic": traffic, "traffic_source": traffic_src}
                 out["roofline_tree"] = tree_roof
                 out["roofline_nn"] = nn_roof
             else:

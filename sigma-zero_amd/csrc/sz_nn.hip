@@ -37,6 +37,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define NN_COUT 256
 #define NN_NI 2                                            // channel tiles (32) per wave
+#define NN_PAD16 32                                        // LDS row padding of the 16x16x32 path (bytes)
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     __bf16 x = (__bf16)a, y = (__bf16)b;                   // v_cvt_pk_bf16_f32: round-to-nearest-even
@@ -47,9 +48,9 @@ __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 
 // ---- stage WGB boards' activations (NHWC rows of C_in bf16) into LDS, plus one zero row ---------------------
-template <int CIN, int WGB>
+template <int CIN, int WGB, int PAD = 16>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards, bool skip) {
-    constexpr int PITCH = CIN * 2 + 16;
+    constexpr int PITCH = CIN * 2 + PAD;
     constexpr int CHUNKS_PER_POS = CIN / 8;                // 16-B chunks per position
     constexpr int TOTAL = WGB * 64 * CHUNKS_PER_POS;
     constexpr int PER_THREAD = TOTAL / 256;
@@ -183,9 +184,9 @@ __device__ __forceinline__ void acc_to_lds(unsigned char* lds, const f32x16 (&ac
 
 // ---- LDS image -> (+ residual) -> (ReLU) -> coalesced 16-byte NHWC stores ------------------------------------
 // The residual is added to the bf16-rounded conv+bias value (torch's own bf16 graph rounds there too).
-template <int WGB>
+template <int WGB, int PAD = 16>
 __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int board0, int n_boards, bool relu) {
-    constexpr int OPITCH = NN_COUT * 2 + 16;
+    constexpr int OPITCH = NN_COUT * 2 + PAD;
     constexpr int OUT_CHUNKS = WGB * 64 * 32;              // 16-byte chunks of the output tile
     const int tid = threadIdx.x;
     const int valid = min(WGB, n_boards - board0) * 64 * 32;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
 // =================================================================================================================
 template <int CIN, int NTAPS, int WGB>
 __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip) {
-    constexpr int PITCH = CIN * 2 + 16;
+    constexpr int PITCH = CIN * 2 + NN_PAD16;             // 34 slots of 16 B per row: (2p + kg) mod 16 is a permutation per lane group
     constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
     constexpr int ZERO_ROW = WGB * 64;
     constexpr int NI = 4, NJ = 4 * WGB, NH = NJ / 2;       // channel tiles, position tiles, position tiles per half-step
@@ -296,7 +297,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 
 template <int WGB>
 __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias, bool relu) {
-    constexpr int OPITCH = NN_COUT * 2 + 16;
+    constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
                                                         const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int flags, int n_cu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int board0 = blockIdx.x * WGB;
-    stage_tile<CIN, WGB>(lds, in, board0, n_boards, (flags & 2) != 0);
+    stage_tile<CIN, WGB, NN_PAD16>(lds, in, board0, n_boards, (flags & 2) != 0);
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
     __syncthreads();
     if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds16<WGB>(lds, acc, bias, false);
     __syncthreads();
-    if (!(flags & 4)) lds_to_out<WGB>(lds, res, out, board0, n_boards, (flags & 1) != 0);
+    if (!(flags & 4)) lds_to_out<WGB, NN_PAD16>(lds, res, out, board0, n_boards, (flags & 1) != 0);
 }
 
 template <int WGB>
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_block16_bf16(const 
                                                          int n_boards, int flags, int n_cu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int board0 = blockIdx.x * WGB;
-    stage_tile<256, WGB>(lds, in, board0, n_boards, false);
+    stage_tile<256, WGB, NN_PAD16>(lds, in, board0, n_boards, false);
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_block16_bf16(const 
     __syncthreads();
     acc_to_lds16<WGB>(lds, acc, b2, false);
     __syncthreads();
-    lds_to_out<WGB>(lds, in, out, board0, n_boards, true);
+    lds_to_out<WGB, NN_PAD16>(lds, in, out, board0, n_boards, true);
 }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
@@ -454,8 +455,8 @@ template <int WGB> static int launch_block(const void* in, const void* w1, const
 }
 
 template <int CIN, int NTAPS> static int launch_conv16(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int flags, hipStream_t s) {
-    constexpr int WGB = 2, PITCH = CIN * 2 + 16;
-    const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + 16);
+    constexpr int WGB = 2, PITCH = CIN * 2 + NN_PAD16;
+    const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + NN_PAD16);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     static bool attr_set = false;
     if (!attr_set) {
@@ -469,7 +470,7 @@ template <int CIN, int NTAPS> static int launch_conv16(const void* in, const voi
 }
 static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
     constexpr int WGB = 2;
-    const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + 16);
+    const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + NN_PAD16);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_block16_bf16<WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
