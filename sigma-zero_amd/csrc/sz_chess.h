@@ -205,7 +205,10 @@ SZ_HD u64 sz_piece_targets(const SzPos& p, const SzInfo& I, int sq) {
         if (m) {
             u64 att = sz_line_att(I.occ, m, sq);
             if (att & kb) {
-                u64 snipers = att & I.them & (p.pc[SZ_Q] | (ortho ? p.pc[SZ_R] : p.pc[SZ_B]));
+                // mask arithmetic instead of `ortho ? rooks : bishops`: hipcc lowers the per-lane select of two
+                // wave-uniform values to a scratch-memory table lookup
+                const u64 om = (u64)0 - (u64)ortho;
+                u64 snipers = att & I.them & (p.pc[SZ_Q] | (p.pc[SZ_R] & om) | (p.pc[SZ_B] & ~om));
                 if (snipers) allowed = m;
             }
         }
@@ -339,7 +342,8 @@ SZ_HD SzPos sz_make_move(const SzPos& q, int from, int to, int promo, int chess9
     u64 fb = sz_bit(from), tb = sz_bit(to);
     u64 occ = sz_all(q), us = white ? q.white : (occ & ~q.white), them = occ & ~us;
     int pt = 0;
-    for (int k = 0; k < 6; k++) if (q.pc[k] & fb) pt = k;
+#pragma unroll
+    for (int k = 0; k < 6; k++) pt = (q.pc[k] & fb) ? k : pt;
     int half = szm_half(q.meta) + 1;
     bool zeroing = (pt == SZ_P) || (them & tb);
     // castling: king takes own rook (Chess960 form) or the classical two-step from the e-file
@@ -366,22 +370,20 @@ SZ_HD SzPos sz_make_move(const SzPos& q, int from, int to, int promo, int chess9
         if (white) p.white = (q.white & ~fb & ~rb) | kto | rto;
         zeroing = false;
     } else {
-        // remove any captured piece on the target
-        for (int k = 0; k < 6; k++) p.pc[k] &= ~tb;
-        p.white &= ~tb;
+        // remove any captured piece on the target; en passant removes the pawn behind it
+        u64 clear = fb | tb;
         if (pt == SZ_P) {
             int diff = to - from;
             if (diff == 16 && (from >> 3) == 1) ep_new = from + 8;
             else if (diff == -16 && (from >> 3) == 6) ep_new = from - 8;
-            else if (to == szm_ep(q.meta) && (diff == 7 || diff == 9 || diff == -7 || diff == -9) && !(occ & tb)) {
-                u64 cap = white ? (tb >> 8) : (tb << 8);
-                p.pc[SZ_P] &= ~cap; p.white &= ~cap;
-            }
+            else if (to == szm_ep(q.meta) && (diff == 7 || diff == 9 || diff == -7 || diff == -9) && !(occ & tb))
+                clear |= white ? (tb >> 8) : (tb << 8);
         }
-        int np = promo ? promo : pt;
-        p.pc[pt] &= ~fb;
-        p.pc[np] |= tb;
-        if (white) p.white = (p.white & ~fb) | tb;
+        const int np = promo ? promo : pt;
+        // no runtime-indexed register arrays (they would live in scratch memory): select with compile-time indices
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.pc[k] = (q.pc[k] & ~clear) | (k == np ? tb : 0ULL);
+        p.white = (q.white & ~clear) | (white ? tb : 0ULL);
     }
     if (zeroing) half = 0;
     if (half > 255) half = 255;

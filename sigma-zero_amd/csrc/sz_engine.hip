@@ -198,25 +198,26 @@ __device__ void wave_encode(const u64* hist_lds, const SzPos& X, void* out_board
     const int lane = lane_id();
     const int vw = szm_turn(X.meta);
     if (dtype == SZ_PLANES_NHWC128_BF16 && out_board) {
-        // NHWC for the custom MFMA stem: lane = position, 128 channels (119 real) = 16 stores of 8 channels
-        const int s = lane ^ sz_view_flip(vw);
-        uint4* dst = (uint4*)out_board + lane * 16;
-        for (int q = 0; q < 16; q++) {
-            uint32_t bits = 0;
+        // NHWC image [64 positions][128 channels] bf16 = 16 KB = 16 wave-instructions of 1 KiB, each fully contiguous:
+        // in store q lane l covers position q*4 + (l>>4), channels (l&15)*8 .. +7.  A lane's 8 channel bitboards do not
+        // depend on q, so they are formed once (8 planes per lane instead of 119) and only shifted per position.
+        const int cq = lane & 15, psub = lane >> 4, flip = sz_view_flip(vw);
+        u64 bb[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int c = q * 8 + k;
-                if (c < SZ_NUM_PLANES) {
-                    u64 bb = (c < 112) ? sz_hist_plane(hist_lds + (c / 14) * 8, c % 14, vw) : sz_aux_plane(X, c - 112);
-                    bits |= (uint32_t)((bb >> s) & 1) << k;
-                }
-            }
+        for (int k = 0; k < 8; k++) {
+            const int c = cq * 8 + k;
+            bb[k] = (c < 112) ? sz_hist_plane(hist_lds + (c / 14) * 8, c % 14, vw) : (c < SZ_NUM_PLANES ? sz_aux_plane(X, c - 112) : 0ULL);
+        }
+        uint4* dst = (uint4*)out_board + lane;
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int sq = (q * 4 + psub) ^ flip;
             uint4 o;
-            o.x = ((bits & 1) ? 0x3F80u : 0u) | ((bits & 2) ? 0x3F800000u : 0u);
-            o.y = ((bits & 4) ? 0x3F80u : 0u) | ((bits & 8) ? 0x3F800000u : 0u);
-            o.z = ((bits & 16) ? 0x3F80u : 0u) | ((bits & 32) ? 0x3F800000u : 0u);
-            o.w = ((bits & 64) ? 0x3F80u : 0u) | ((bits & 128) ? 0x3F800000u : 0u);
-            dst[q] = o;
+            o.x = (((bb[0] >> sq) & 1) ? 0x3F80u : 0u) | (((bb[1] >> sq) & 1) ? 0x3F800000u : 0u);
+            o.y = (((bb[2] >> sq) & 1) ? 0x3F80u : 0u) | (((bb[3] >> sq) & 1) ? 0x3F800000u : 0u);
+            o.z = (((bb[4] >> sq) & 1) ? 0x3F80u : 0u) | (((bb[5] >> sq) & 1) ? 0x3F800000u : 0u);
+            o.w = (((bb[6] >> sq) & 1) ? 0x3F80u : 0u) | (((bb[7] >> sq) & 1) ? 0x3F800000u : 0u);
+            dst[q * 64] = o;
         }
         if (!packed_out) return;
         out_board = nullptr;

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
 }
 
 template <int WGB>
-__global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_block16_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w1, const float* __restrict__ b1,
+__global__ __launch_bounds__(256, (WGB == 2 ? 2 : (WGB == 1 ? 3 : 1))) void k_block16_bf16(const uint16_t* __restrict__ in, const uint4* __restrict__ w1, const float* __restrict__ b1,
                                                          const uint4* __restrict__ w2, const float* __restrict__ b2, uint16_t* __restrict__ out,
                                                          int n_boards, int flags, int n_cu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -468,8 +468,7 @@ template <int CIN, int NTAPS> static int launch_conv16(const void* in, const voi
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
-static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
-    constexpr int WGB = 2;
+template <int WGB> static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
     const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + NN_PAD16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -510,7 +509,8 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
 int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* out,
                      int32_t n_boards, int32_t flags, void* stream) {
     if (!in || !w1_packed || !bias1 || !w2_packed || !bias2 || !out || in == out || n_boards <= 0) return SZ_ERR_INVALID;
-    if (flags & SZ_NN_W16) return launch_block16(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
+    if (flags & SZ_NN_W16) return (flags & 0x80000) ? launch_block16<1>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream)   // A/B: 1-board workgroups, 3-4 per CU
+                                                    : launch_block16<2>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
     return launch_block<2>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
 }
 

@@ -54,6 +54,11 @@ for B in (512, 4096):
         N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, N.SZ_NN_W16, st)
     dt = timeit(runb16)
     print("fused block mfma16 B=%d: %.3f ms  %.1f TFLOP/s" % (B, dt * 1e3, 2 * fl / dt / 1e12))
+    def runb16_1():
+        N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w16a.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, N.SZ_NN_W16 | 0x80000, st)
+    for rep in range(2):
+        dt = timeit(runb16_1); dt2 = timeit(runb16)
+        print("fused block mfma16 1-board WGs B=%d: %.3f ms  (2-board: %.3f ms)" % (B, dt * 1e3, dt2 * 1e3))
     w2 = _pack(torch.randn(256, 256, 3, 3) * 0.02, 256, 3, "cuda")
     def runb():
         N.lib().sz_nn_block_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, 0, st)
