@@ -146,6 +146,15 @@ int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, 
 
 int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
 
+/* Heads of policyNN (network.py:141-174) as two small kernels:
+ *  policy: t = relu(bn(conv_p1(x))) [n_boards,64,256] bf16 -> conv_p2 + bias -> (softmax) -> probs [n_boards,4672] f32 in the
+ *          reference's flatten order (plane*64 + row*8 + col); w_packed from sz_nn_pack_head16(conv_p2.weight [73,256]);
+ *  value : x [n_boards,64,256] bf16 -> conv_v1 (+v_norm folded: wv[256], bv) -> ReLU -> fc_v1 -> ReLU -> fc_v2 -> tanh -> [n_boards]. */
+int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bias, float* probs, int32_t n_boards, int32_t do_softmax, void* stream);
+int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
+                          float* value, int32_t n_boards, void* stream);
+int sz_nn_pack_head16(const float* w_in, uint16_t* out);
+
 const char* sz_error_string(int code);
 int sz_device_count(void);
 

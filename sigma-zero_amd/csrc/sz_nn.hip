@@ -408,6 +408,114 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : (WGB == 1 ? 3 : 1))) void k_bl
     lds_to_out<WGB, NN_PAD16>(lds, in, out, board0, n_boards, true);
 }
 
+// =================================================================================================================
+// Heads (network.py:141-174).  Small, memory-bound kernels that replace ~12 torch launches per forward.
+//   k_policy_head : logits[73][64] = Wp2 x t^T + b  (t = relu(bn(conv_p1(x))) from k_conv16<256,1>), softmax over the
+//                   4672 logits, written as f32 in the reference's flatten order [plane*64 + pos].  One wave per board:
+//                   5 channel tiles(16) x 4 position tiles(16) of v_mfma_f32_16x16x32_bf16, K = 256.
+//   k_value_head  : v = tanh(fc2(relu(fc1(relu(bn(conv_v1(x)))))));  one wave per board, lane = position.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_policy_head(const uint16_t* __restrict__ t, const uint4* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ probs, int n_boards, int do_softmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int board = blockIdx.x * 4 + wave;
+    if (board >= n_boards) return;
+    const int p16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint16_t* tb = t + (size_t)board * 64 * 256;
+#pragma unroll 2
+    for (int kc = 0; kc < 8; kc++) {
+        bf16x8 a[5], b[4];
+#pragma unroll
+        for (int i = 0; i < 5; i++) a[i] = __builtin_bit_cast(bf16x8, w[(size_t)(kc * 5 + i) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = *(const bf16x8*)(tb + (size_t)(j * 16 + p16) * 256 + kc * 32 + kg * 8);
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    // lane holds logits for position j*16+p16 and channels i*16 + 4*kg + r
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int co = i * 16 + 4 * kg + r;
+            const float bv = co < 73 ? bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[i][j][r] += bv;
+                if (co < 73) mx = fmaxf(mx, acc[i][j][r]);
+            }
+        }
+    float sum = 0.f;
+    if (do_softmax) {
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = i * 16 + 4 * kg + r;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float e = co < 73 ? __expf(acc[i][j][r] - mx) : 0.f;
+                    acc[i][j][r] = e;
+                    sum += e;
+                }
+            }
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    }
+    const float inv = do_softmax ? 1.0f / sum : 1.0f;
+    float* pb = probs + (size_t)board * 4672;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int co = i * 16 + 4 * kg + r;
+            if (co < 73) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) pb[co * 64 + j * 16 + p16] = acc[i][j][r] * inv;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__ x, const float* __restrict__ wv, float bv, const float* __restrict__ fc1_w /*[64][256]*/,
+                                                     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float fc2_b, float* __restrict__ value, int n_boards) {
+    __shared__ float v1s[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int board = blockIdx.x * 4 + wave;
+    const bool live = board < n_boards;
+    float dot = 0.f;
+    if (live) {
+        const uint4* row = (const uint4*)(x + ((size_t)board * 64 + lane) * 256);
+#pragma unroll 4
+        for (int c = 0; c < 32; c++) {
+            uint4 v = row[c];
+            const float* wc = wv + c * 8;
+            dot += bf16_lo(v.x) * wc[0] + bf16_hi(v.x) * wc[1] + bf16_lo(v.y) * wc[2] + bf16_hi(v.y) * wc[3] +
+                   bf16_lo(v.z) * wc[4] + bf16_hi(v.z) * wc[5] + bf16_lo(v.w) * wc[6] + bf16_hi(v.w) * wc[7];
+        }
+    }
+    v1s[wave][lane] = fmaxf(dot + bv, 0.f);                // relu(bn(conv_v1)) for position `lane`
+    __syncthreads();
+    if (!live) return;
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                           // fc1 outputs j = lane + 64 q
+        const int j = lane + 64 * q;
+        float h = fc1_b[j];
+        for (int p = 0; p < 64; p++) h += v1s[wave][p] * fc1_w[p * 256 + j];
+        part += fmaxf(h, 0.f) * fc2_w[j];
+    }
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) value[board] = tanhf(part + fc2_b);
+}
+
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
 static int device_cus() {
@@ -530,6 +638,39 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
                         uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
                         out[((((size_t)t * ksteps + ks) * 16 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
                     }
+    return SZ_OK;
+}
+
+// Policy head (network.py:141-154 after conv_p1): t [n_boards,64,256] bf16 -> probs [n_boards,4672] f32 (softmax iff do_softmax).
+// w_packed from sz_nn_pack_head16 (73 output channels padded to 80), bias [73] f32.
+int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bias, float* probs, int32_t n_boards, int32_t do_softmax, void* stream) {
+    if (!t || !w_packed || !bias || !probs || n_boards <= 0) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_policy_head, dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)t, (const uint4*)w_packed, bias, probs, n_boards, do_softmax);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+// Value head (network.py:156-174): x [n_boards,64,256] bf16 (tower output) -> value [n_boards] f32.
+// wv [256] f32 and bv: conv_v1 with v_norm folded; fc1_w_t [64][256] f32 (fc_v1.weight transposed), fc1_b [256], fc2_w [256], fc2_b.
+int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
+                          float* value, int32_t n_boards, void* stream) {
+    if (!x || !wv || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_value_head, dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+// host: conv_p2.weight [73][256] f32 -> [8 k32-steps][5 co tiles][64 lanes][8] bf16 (channels 73..79 zero)
+int sz_nn_pack_head16(const float* w_in, uint16_t* out) {
+    if (!w_in || !out) return SZ_ERR_INVALID;
+    for (int ks = 0; ks < 8; ks++)
+        for (int tile = 0; tile < 5; tile++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
+                    float v = co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f;
+                    uint32_t u; memcpy(&u, &v, 4);
+                    uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+                    out[(((size_t)ks * 5 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
+                }
     return SZ_OK;
 }
 

@@ -64,6 +64,16 @@ class FastPolicyNet:
         self.fc1_b = model.fc_v1.bias.detach().float().to(dev)
         self.fc2_w = model.fc_v2.weight.detach().float().t().contiguous().to(dev)
         self.fc2_b = model.fc_v2.bias.detach().float().to(dev)
+        # native heads (csrc/sz_nn.hip k_policy_head / k_value_head): packed conv_p2, folded conv_v1, fc weights in f32
+        wp2 = model.conv_p2.weight.detach().view(73, 256).contiguous().cpu().float().numpy()
+        packed = np.zeros(8 * 5 * 64 * 8, dtype=np.uint16)
+        N.check(N.lib().sz_nn_pack_head16(wp2.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "sz_nn_pack_head16")
+        self.wp2_packed = torch.from_numpy(packed.view(np.int16)).to(dev)
+        self.wv_f32 = wv.view(256).contiguous().to(dev)
+        self.bv_f = float(bv.view(-1)[0])
+        self.fc2_w_vec = self.fc2_w.view(256).contiguous()
+        self.fc2_b_f = float(self.fc2_b.view(-1)[0])
+        self.native_heads = True
         self._bufs = {}
         self.fuse_blocks = True      # one launch per BasicBlock (sz_nn_block_bf16); False = two sz_nn_conv_bf16 launches
         self.timing = None          # optional list: (start, end) HIP event pairs around every 3x3 C_in=256 conv launch
@@ -98,7 +108,7 @@ class FastPolicyNet:
     def tower(self, planes):
         """planes [B,64,128] bf16 NHWC -> tower output [B,64,256] bf16 NHWC"""
         B = planes.shape[0]
-        a, t, c = self._buffers(B)
+        a, t, c = self._buffers(B)[:3]
         self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3)
         for (w1, b1, w2, b2) in self.blocks:
             if self.fuse_blocks:
@@ -126,6 +136,18 @@ class FastPolicyNet:
         B = planes.shape[0]
         x, scratch = self.tower(planes)
         self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
+        if self.native_heads:
+            if B not in self._bufs or len(self._bufs[B]) < 5:
+                self._bufs[B] = self._bufs[B][:3] + [torch.empty(B, 4672, dtype=torch.float32, device=self.device),
+                                                     torch.empty(B, dtype=torch.float32, device=self.device)]
+            policy, value = self._bufs[B][3], self._bufs[B][4]
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            N.check(N.lib().sz_nn_policy_head_bf16(C.c_void_p(scratch.data_ptr()), C.c_void_p(self.wp2_packed.data_ptr()), C.c_void_p(self.bp2.data_ptr()),
+                                                   C.c_void_p(policy.data_ptr()), B, int(bool(inference)), st), "sz_nn_policy_head_bf16")
+            N.check(N.lib().sz_nn_value_head_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(self.wv_f32.data_ptr()), self.bv_f, C.c_void_p(self.fc1_w.data_ptr()),
+                                                  C.c_void_p(self.fc1_b.data_ptr()), C.c_void_p(self.fc2_w_vec.data_ptr()), self.fc2_b_f,
+                                                  C.c_void_p(value.data_ptr()), B, st), "sz_nn_value_head_bf16")
+            return policy, value.view(B, 1)
         logits = torch.matmul(scratch.view(B * 64, 256), self.wp2).float().view(B, 64, 73) + self.bp2        # [B,pos,plane]
         logits = logits.transpose(1, 2).reshape(B, 73 * 64)                                                  # flatten of [73,8,8]
         policy = torch.softmax(logits, dim=1) if inference else logits
