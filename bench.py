@@ -265,7 +265,7 @@ def main():
             else:
                 out["roofline"] = tree_roof
                 out["roofline_nn"] = nn_roof
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (bounded ~15 s sample)
             out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out))
     if dist is not None:

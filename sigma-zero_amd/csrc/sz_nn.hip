@@ -484,36 +484,53 @@ __global__ __launch_bounds__(256) void k_policy_head(const uint16_t* __restrict_
         }
 }
 
+#define VH_BOARDS_PER_WAVE 4
 __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__ x, const float* __restrict__ wv, float bv, const float* __restrict__ fc1_w /*[64][256]*/,
                                                      const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float fc2_b, float* __restrict__ value, int n_boards) {
-    __shared__ float v1s[4][64];
+    // workgroup = 4 waves x 4 boards each; fc_v1's 64 KB weight matrix is staged in LDS once per workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char vh_lds[];
+    float* w1s = (float*)vh_lds;                            // [64][256]
+    float* v1s = w1s + 64 * 256;                            // [4 waves][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int board = blockIdx.x * 4 + wave;
-    const bool live = board < n_boards;
-    float dot = 0.f;
-    if (live) {
-        const uint4* row = (const uint4*)(x + ((size_t)board * 64 + lane) * 256);
-#pragma unroll 4
-        for (int c = 0; c < 32; c++) {
-            uint4 v = row[c];
-            const float* wc = wv + c * 8;
-            dot += bf16_lo(v.x) * wc[0] + bf16_hi(v.x) * wc[1] + bf16_lo(v.y) * wc[2] + bf16_hi(v.y) * wc[3] +
-                   bf16_lo(v.z) * wc[4] + bf16_hi(v.z) * wc[5] + bf16_lo(v.w) * wc[6] + bf16_hi(v.w) * wc[7];
-        }
-    }
-    v1s[wave][lane] = fmaxf(dot + bv, 0.f);                // relu(bn(conv_v1)) for position `lane`
-    __syncthreads();
-    if (!live) return;
-    float part = 0.f;
+    for (int c = threadIdx.x; c < 64 * 256 / 4; c += 256) ((float4*)w1s)[c] = ((const float4*)fc1_w)[c];
+    float wreg[8], b1r[4], w2r[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {                           // fc1 outputs j = lane + 64 q
-        const int j = lane + 64 * q;
-        float h = fc1_b[j];
-        for (int p = 0; p < 64; p++) h += v1s[wave][p] * fc1_w[p * 256 + j];
-        part += fmaxf(h, 0.f) * fc2_w[j];
+    for (int k = 0; k < 8; k++) wreg[k] = wv[(lane & 31) * 8 + k];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { b1r[q] = fc1_b[lane + 64 * q]; w2r[q] = fc2_w[lane + 64 * q]; }
+    __syncthreads();
+    for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++) {
+        const int board = (blockIdx.x * 4 + wave) * VH_BOARDS_PER_WAVE + bi;
+        if (board >= n_boards) break;
+        // coalesced: the board's 32 KB tile is read as 32 contiguous 1 KiB pieces; in piece i lane l holds channels
+        // (l&31)*8..+7 of position 2i + (l>>5); the 32 lanes of a position are summed with an xor butterfly
+        const uint4* tile = (const uint4*)(x + (size_t)board * 64 * 256);
+        float dot = 0.f;                                    // lane p ends up with the conv_v1 output of position p
+#pragma unroll 8
+        for (int i = 0; i < 32; i++) {
+            uint4 v = tile[i * 64 + lane];
+            float part = bf16_lo(v.x) * wreg[0] + bf16_hi(v.x) * wreg[1] + bf16_lo(v.y) * wreg[2] + bf16_hi(v.y) * wreg[3] +
+                         bf16_lo(v.z) * wreg[4] + bf16_hi(v.z) * wreg[5] + bf16_lo(v.w) * wreg[6] + bf16_hi(v.w) * wreg[7];
+            for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+            const float lo = __shfl(part, 0), hi = __shfl(part, 32);
+            if (lane == 2 * i) dot = lo;
+            if (lane == 2 * i + 1) dot = hi;
+        }
+        v1s[wave * 64 + lane] = fmaxf(dot + bv, 0.f);       // relu(bn(conv_v1)) for position `lane`
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the wave's own LDS writes have landed
+        float h[4] = {b1r[0], b1r[1], b1r[2], b1r[3]};
+        for (int p = 0; p < 64; p++) {
+            const float vp = v1s[wave * 64 + p];
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[q] += vp * w1s[p * 256 + lane + 64 * q];
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) part += fmaxf(h[q], 0.f) * w2r[q];
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) value[board] = tanhf(part + fc2_b);
     }
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0) value[board] = tanhf(part + fc2_b);
 }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
@@ -654,7 +671,14 @@ int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bia
 int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
                           float* value, int32_t n_boards, void* stream) {
     if (!x || !wv || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
-    hipLaunchKernelGGL(k_value_head, dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards);
+    const size_t lds = (64 * 256 + 4 * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int per_wg = 4 * VH_BOARDS_PER_WAVE;
+    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
