@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--chess960", type=int, default=0)
     ap.add_argument("--net", default="fast", choices=["fast", "torch"],
                     help="fast: hand-written MFMA conv tower (csrc/sz_nn.hip); torch: MIOpen/ATen kernels")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
@@ -120,12 +121,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the search path has no CPU fallback")
+    if a.dist_backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.dist_backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import sigma_zero_amd as sz
     from sigma_zero_amd.selfplay import SelfPlayEngine
@@ -203,7 +209,7 @@ def main():
     sum_depth = st1["sum_depth"] - st0["sum_depth"]
     sum_k = st1["sum_children"] - st0["sum_children"]
     from sigma_zero_amd.train_rl import aggregate_throughput
-    (total_sims, total_exps), dt_max = aggregate_throughput([sims, exps], dt, device=dev)
+    (total_sims, total_exps), dt_max = aggregate_throughput([sims, exps], dt, device="cpu" if a.dist_backend == "gloo" else dev)
 
     if rank == 0:
         out = {
