@@ -107,7 +107,8 @@ int sz_root_children(sz_engine* e, int32_t* action_dev, int32_t* visits_dev, int
 /* sim.py:68-76: sample a move per board from the visit distribution exactly like
  * np.random.choice(keys, p=visits/sum) given the uniform it draws (uniforms_dev [n_boards] f64),
  * record the training sample of this ply, play the move into the board's game and test
- * board.is_game_over() (sim.py:46). */
+ * board.is_game_over() (sim.py:46).  A negative uniform selects the most visited child instead
+ * (max(action_probs, key=...) of eval.py:92-94 / play.py:40-41: first maximum in action-index order). */
 int sz_play(sz_engine* e, const double* uniforms_dev, void* stream);
 
 /* Copy this ply's training records to host arrays (synchronises; any pointer may be NULL):

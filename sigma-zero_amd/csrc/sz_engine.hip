@@ -571,6 +571,10 @@ __global__ __launch_bounds__(64) void k_play(View v, const double* uniforms) {
         int idx = 0;
         for (int c = 0; c < n; c++) { acc += (double)vis_lds[c] / (double)total; if (acc / last <= u) idx = c + 1; }
         if (idx >= n) idx = n - 1;
+        if (u < 0.0) {                                                  // greedy: max(action_probs, key=...) of eval.py:92-94 — first maximum
+            idx = 0;
+            for (int c = 1; c < n; c++) if (vis_lds[c] > vis_lds[idx]) idx = c;
+        }
         chosen = idx;
     }
     chosen = uni(chosen);

@@ -340,3 +340,32 @@ def test_inactive_and_ragged_boards():
     rec = eng.fetch_ply()
     assert rec["active"].tolist() == active
     eng.close()
+
+
+def test_arena_greedy_match():
+    """model-vs-model gating (test_update.py semantics): greedy play, learning off; a model against itself with mirrored
+    colours must produce mirrored results (the search is deterministic)."""
+    from sigma_zero_amd.arena import play_match
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    out = play_match(net, net, {"C": 2, "num_searches": 6}, n_games=4, max_plies=10)
+    assert out["a_wins"] + out["b_wins"] + out["draws"] + out["unfinished"] == 4
+    # boards 0 and 2 (same colours, same deterministic play) agree, and so do boards 1 and 3
+    assert out["results"][0] == out["results"][2] and out["results"][1] == out["results"][3]
+    # greedy = first maximum: check against the oracle on one position
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": 12}, 2, learning=False)
+    eng.new_games([-1, -1])
+    ev = random_evaluator(4)
+    oct_ = O.ChessTensor()
+    s = O.Search.on_chess(oct_, c=2.0, num_searches=12, learning=False)
+    eng.begin()
+    for step in range(12):
+        p, v = ev(eng.planes, step)
+        if s.advance():
+            s.feed(p[0].cpu().numpy(), float(v[0]))
+        eng.step(p, v)
+    eng.play(np.array([-1.0, 0.3]))
+    rec = eng.fetch_ply()
+    idx, vis, _ = s.root_children()
+    assert int(rec["chosen"][0]) == idx[int(np.argmax(vis))]
+    eng.close()
