@@ -147,6 +147,12 @@ int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, 
 
 int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
 
+/* The whole tower (network.py:176-184: stem conv + n_blocks BasicBlocks) in ONE persistent launch: a workgroup keeps its
+ * boards' activations in LDS through all 1 + 2*n_blocks convolutions; only weights stream.  planes [n_boards,64,128] bf16
+ * (SZ_PLANES_NHWC128_BF16), out [n_boards,64,256] bf16; w_packed / bias: HOST arrays of 1 + 2*n_blocks DEVICE pointers
+ * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128). */
+int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
+                     int32_t n_boards, void* stream);
 /* Heads of policyNN (network.py:141-174) as two small kernels:
  *  policy: t = relu(bn(conv_p1(x))) [n_boards,64,256] bf16 -> conv_p2 + bias -> (softmax) -> probs [n_boards,4672] f32 in the
  *          reference's flatten order (plane*64 + row*8 + col); w_packed from sz_nn_pack_head16(conv_p2.weight [73,256]);

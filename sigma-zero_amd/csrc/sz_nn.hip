@@ -221,14 +221,28 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
 //   weights (4 fragments per k-step) ride a 2-deep ring one k-step ahead, activations are double-buffered one
 //   half-step ahead.  Weight order: [tap][k32][co_tile16][lane][8] (sz_nn_pack_weights16).
 // =================================================================================================================
-template <int CIN, int NTAPS, int WGB>
-__device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip) {
+// first PF k-steps of a convolution's weight stream into the ring (issued early, e.g. under the previous layer's epilogue)
+template <int RING>
+__device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uint4 (&aring)[RING][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint4* wbase = w + (size_t)(wave * 4) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < RING - 1; s++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) aring[s][i] = wbase[(size_t)s * (16 * 64) + i * 64];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false>
+__device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip, bool wprobe = false,
+                                             uint4 (*ring_in)[4] = nullptr) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;             // 34 slots of 16 B per row: (2p + kg) mod 16 is a permutation per lane group
     constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
     constexpr int ZERO_ROW = WGB * 64;
     constexpr int NI = 4, NJ = 4 * WGB, NH = NJ / 2;       // channel tiles, position tiles, position tiles per half-step
     constexpr int TOTAL_KS = NTAPS * KSTEPS;
-    constexpr int W_KSTEP_STRIDE = 16 * 64;                // uint4 per (tap,k32)
+    const int W_KSTEP_STRIDE = wprobe ? 0 : 16 * 64;       // uint4 per (tap,k32); 0 = timing probe: every k-step re-reads the same (L1-hot) fragments
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
     const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
@@ -236,9 +250,16 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 aring[2][NI];
+    constexpr int PF = RING - 1;                           // weight prefetch distance in k-steps (512 matrix-pipe cycles each)
+    static_assert(KSTEPS % RING == 0, "ring slots must be compile-time indices");
+    uint4 aring[RING][NI];
 #pragma unroll
-    for (int i = 0; i < NI; i++) aring[0][i] = wbase[i * 64];
+    for (int s = 0; s < PF; s++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            if constexpr (PREFETCHED) aring[s][i] = ring_in[s][i];
+            else aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
+        }
     auto tap_addr = [&](int tap, int j) -> int {
         const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
         int pos = (j & 3) * 16 + p16;                      // position inside its board (board = j >> 2)
@@ -263,9 +284,9 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
             const int ks = tap * KSTEPS + kc;
 #pragma unroll
             for (int hs = 0; hs < 2; hs++) {
-                if (hs == 0 && ks + 1 < TOTAL_KS) {         // weights of the next k-step (slot freed by the previous half-step)
+                if (hs == 0 && ks + PF < TOTAL_KS) {        // weights PF k-steps ahead (slot freed by the previous half-step)
 #pragma unroll
-                    for (int i = 0; i < NI; i++) aring[(kc + 1) & 1][i] = wbase[(size_t)(ks + 1) * W_KSTEP_STRIDE + i * 64];
+                    for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
                 }
                 // activations of the next half-step
                 if (hs == 0) {
@@ -282,7 +303,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
-                    bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & 1][i]);
+                    bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++)
                         acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], acc[i][hs * NH + j], 0, 0, 0);
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
-    conv_kloop16<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0);
+    conv_kloop16<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0, (flags & 0x100000) != 0);
     __syncthreads();
     if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds16<WGB>(lds, acc, bias, false);
     __syncthreads();
@@ -533,6 +554,82 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
     }
 }
 
+// x <- relu(acc + bias + x) in place on the LDS image (f32 add, one bf16 rounding): every lane owns its 4 channels x 1 position
+template <int WGB>
+__device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias) {
+    constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4 * WGB; j++) {
+        const int row = (j >> 2) * 64 + (j & 3) * 16 + p16;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int co = (wave * 4 + i) * 16 + 4 * kg;
+            f32x4 b4 = *(const f32x4*)(bias + co);
+            uint2* px = (uint2*)(xlds + row * OPITCH + co * 2);
+            const uint2 r = *px;
+            float v0 = fmaxf(acc[i][j][0] + b4[0] + bf16_lo(r.x), 0.f), v1 = fmaxf(acc[i][j][1] + b4[1] + bf16_hi(r.x), 0.f);
+            float v2 = fmaxf(acc[i][j][2] + b4[2] + bf16_lo(r.y), 0.f), v3 = fmaxf(acc[i][j][3] + b4[3] + bf16_hi(r.y), 0.f);
+            uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+            *px = o;
+        }
+    }
+}
+
+// =================================================================================================================
+// Whole tower in ONE persistent launch (network.py:176-184: stem + 19 BasicBlocks).  A workgroup (4 waves, one per
+// SIMD, one workgroup per CU) takes a 2-board tile through all 39 convolutions: the running activation x and the
+// block-internal activation t live in two LDS images (2 x 70 KB), so between the NHWC planes read by the stem and the
+// tower output nothing but WEIGHTS moves: no per-layer tile loads/stores (5 GB of HBM traffic per forward at B=4096),
+// no launch boundaries, the residual is added in f32 from LDS.  With the whole register file per wave the weight ring is
+// 4 deep (3 k-steps = 1536 matrix-pipe cycles ahead).  Measured: wins at small batches (B=512: 1.02 vs 1.20 ms per forward),
+// loses 2 % to the per-block kernels at B=4096 (an 8-wave, two-waves-per-SIMD variant lost 7 %): FastPolicyNet picks by batch size.
+// =================================================================================================================
+#define NN_MAX_CONVS 40
+struct TowerParams {
+    const uint4* w[NN_MAX_CONVS];                          // [0] stem (C_in 128), then conv1, conv2 of each block (16x16x32 fragment order)
+    const float* b[NN_MAX_CONVS];
+};
+
+__global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks) {
+    constexpr int WGB = 2;
+    constexpr int IMG = (WGB * 64 + 1) * (NN_COUT * 2 + NN_PAD16);       // one activation image incl. its zero row
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* bufX = lds;
+    unsigned char* bufT = lds + IMG;
+    const int n_tiles = (n_boards + WGB - 1) / WGB;
+    // zero rows of both 256-channel images (row index 128); the stem's own zero row is rewritten by stage_tile
+    for (int c = threadIdx.x; c < (NN_COUT * 2 + NN_PAD16) / 16; c += 256) {
+        *(uint4*)(bufX + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(bufT + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+    f32x4 acc[4][4 * WGB];
+    uint4 ring[4][4];                                                  // next convolution's first weight fragments, fetched under the current epilogue
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int board0 = tile * WGB;
+        conv_prefetch16<4>(prm.w[0], ring);
+        __syncthreads();                                               // previous tile's output image fully read
+        stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
+        __syncthreads();
+        conv_kloop16<128, 9, WGB, 4, true>(bufT, prm.w[0], acc, false, false, ring);     // stem: x = relu(bn(conv1(planes)))
+        if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
+        acc_to_lds16<WGB>(bufX, acc, prm.b[0], true);
+        __syncthreads();
+        for (int blk = 0; blk < n_blocks; blk++) {
+            conv_kloop16<256, 9, WGB, 4, true>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring);
+            conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
+            acc_to_lds16<WGB>(bufT, acc, prm.b[1 + 2 * blk], true);   // t = relu(bn1(conv1(x)))   (bufT is idle: last read before the barrier above)
+            __syncthreads();
+            conv_kloop16<256, 9, WGB, 4, true>(bufT, prm.w[2 + 2 * blk], acc, false, false, ring);
+            if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
+            acc_residual_inplace16<WGB>(bufX, acc, prm.b[2 + 2 * blk]);   // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+            __syncthreads();
+        }
+        lds_to_out<WGB, NN_PAD16>(bufX, nullptr, out, board0, n_boards, false);
+    }
+}
+
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
 static int device_cus() {
@@ -655,6 +752,29 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
                         uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
                         out[((((size_t)t * ksteps + ks) * 16 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
                     }
+    return SZ_OK;
+}
+
+// Whole tower (stem + n_blocks BasicBlocks) in one persistent launch.  planes [n_boards,64,128] bf16 (NHWC, 119 real channels),
+// out [n_boards,64,256] bf16.  w/b: n_convs = 1 + 2*n_blocks device pointers each (weights from sz_nn_pack_weights16, stem with
+// cin_padded 128; biases [256] f32 with BatchNorm folded), given as HOST arrays of device pointers.
+int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out, int32_t n_boards, void* stream) {
+    if (!planes || !w_packed || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS) return SZ_ERR_INVALID;
+    TowerParams prm;
+    memset(&prm, 0, sizeof prm);
+    for (int i = 0; i < 1 + 2 * n_blocks; i++) {
+        if (!w_packed[i] || !bias[i]) return SZ_ERR_INVALID;
+        prm.w[i] = (const uint4*)w_packed[i]; prm.b[i] = bias[i];
+    }
+    const size_t lds = 2 * (size_t)(2 * 64 + 1) * (NN_COUT * 2 + NN_PAD16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
+    hipLaunchKernelGGL(k_tower16_bf16, dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks);
+    HIPCHK(hipGetLastError());
     return SZ_OK;
 }
 

@@ -74,6 +74,14 @@ class FastPolicyNet:
         self.fc2_w_vec = self.fc2_w.view(256).contiguous()
         self.fc2_b_f = float(self.fc2_b.view(-1)[0])
         self.native_heads = True
+        # whole-tower persistent kernel (sz_nn_tower_bf16): host arrays of device pointers, 16x16x32 weight order only
+        self.persistent_tower = self.w16
+        self.persistent_max_boards = 1024     # measured: one launch for the whole tower wins at small batches, per-block launches at 4096
+        if self.w16:
+            ws = [self.stem[0]] + [w for blk in self.blocks for w in (blk[0], blk[2])]
+            bs = [self.stem[1]] + [b for blk in self.blocks for b in (blk[1], blk[3])]
+            self._tower_w = (C.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+            self._tower_b = (C.c_void_p * len(bs))(*[t.data_ptr() for t in bs])
         self._bufs = {}
         self.fuse_blocks = True      # one launch per BasicBlock (sz_nn_block_bf16); False = two sz_nn_conv_bf16 launches
         self.timing = None          # optional list: (start, end) HIP event pairs around every 3x3 C_in=256 conv launch
@@ -109,6 +117,17 @@ class FastPolicyNet:
         """planes [B,64,128] bf16 NHWC -> tower output [B,64,256] bf16 NHWC"""
         B = planes.shape[0]
         a, t, c = self._buffers(B)[:3]
+        if self.persistent_tower and (B <= self.persistent_max_boards):
+            ev = None
+            if self.timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B,
+                                             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_bf16")
+            if ev is not None:
+                ev[1].record()
+                self.timing.append(ev)
+            return a, t
         self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3)
         for (w1, b1, w2, b2) in self.blocks:
             if self.fuse_blocks:

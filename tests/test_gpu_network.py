@@ -93,6 +93,16 @@ def test_fast_network_matches_fp32_policynn(mfma16):
             m.weight.data.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g, device="cuda") * 0.1)
     fast = FastPolicyNet(net, mfma16=mfma16)
+    if mfma16:
+        # the persistent whole-tower kernel against the per-block kernels (same weights; the only numeric difference is
+        # the residual add: f32 from LDS vs. after a bf16 rounding)
+        xin = planes_nchw_to_nhwc128((torch.rand(9, 119, 8, 8, generator=g, device="cuda") < 0.12).float())
+        assert fast.persistent_tower and xin.shape[0] <= fast.persistent_max_boards
+        y_p = fast.tower(xin)[0].float().clone()
+        fast.persistent_tower = False
+        y_b = fast.tower(xin)[0].float().clone()
+        fast.persistent_tower = True
+        assert float((y_p - y_b).norm() / y_b.norm()) < 0.02
     x = (torch.rand(37, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
     with torch.no_grad():
         p_ref, v_ref = net(x, inference=True)

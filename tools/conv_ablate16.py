@@ -17,6 +17,6 @@ def mk(mode, r=None):
         N.lib().sz_nn_conv_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()) if r else None, C.c_void_p(out.data_ptr()), B, 256, 3, mode | N.SZ_NN_W16, st)
     return f
 for rep in range(2):
-    for mode, name in ((1, "full"), (1 | 0x10000, "full, no stagger"), (1 | 32 | (1 << 8), "stagger n=1"), (1 | 32 | (6 << 8), "stagger n=6"), (3, "no tile load"), (5, "no store"), (7, "K loop only (zeros)"), (5 | 0, "load+K (real data)"), (9, "no K loop")):
+    for mode, name in ((1, "full"), (1 | 0x100000, "full, L1-hot weights"), (1 | 0x10000, "full, no stagger"), (1 | 32 | (1 << 8), "stagger n=1"), (1 | 32 | (6 << 8), "stagger n=6"), (3, "no tile load"), (5, "no store"), (7, "K loop only (zeros)"), (5 | 0, "load+K (real data)"), (9, "no K loop")):
         print("%-22s %.3f ms" % (name, timeit(mk(mode)) * 1e3))
     print("full+res               %.3f ms" % (timeit(mk(1, True)) * 1e3))

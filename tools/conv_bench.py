@@ -73,5 +73,13 @@ for B in (512, 4096):
     print("FastPolicyNet B=%d: %.2f ms  %.1f TFLOP/s  %.0f evals/s" % (B, dt * 1e3, B * FLOPS_PER_BOARD / dt / 1e12, B / dt))
     dt = timeit(lambda: fast32(planes, inference=True), n=10)
     print("FastPolicyNet(mfma32) B=%d: %.2f ms  %.1f TFLOP/s  %.0f evals/s" % (B, dt * 1e3, B * FLOPS_PER_BOARD / dt / 1e12, B / dt))
+    for rep in range(2):
+        fast.persistent_tower = False
+        dt = timeit(lambda: fast(planes, inference=True), n=10)
+        print("FastPolicyNet(per-block launches) B=%d: %.2f ms  %.0f evals/s" % (B, dt * 1e3, B / dt))
+        fast.persistent_tower = True; fast.persistent_max_boards = 1 << 30
+        dt = timeit(lambda: fast(planes, inference=True), n=10)
+        print("FastPolicyNet(persistent tower) B=%d: %.2f ms  %.0f evals/s" % (B, dt * 1e3, B / dt))
+        fast.persistent_max_boards = 1024
     dt = timeit(lambda: fast.tower(planes), n=10)
     print("  tower only: %.2f ms" % (dt * 1e3))
