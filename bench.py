@@ -252,16 +252,20 @@ def main():
                 # per launch, or k_conv_bf16<256,9> when block fusion is off
                 conv_ms = float(np.mean([s.elapsed_time(e) for s, e in conv_events]))
                 fused = getattr(model, "fuse_blocks", False)
+                whole = getattr(model, "persistent_tower", False) and B <= getattr(model, "persistent_max_boards", 0)
                 conv_flop = 2.0 * B * 64 * 256 * 2304 * (2 if fused else 1)
+                if whole:                                   # stem (119 real input planes) + 38 tower convolutions in one launch
+                    conv_flop = 2.0 * B * 64 * 256 * 9 * (119 + 38 * 256)
                 ctf = conv_flop / (conv_ms * 1e-3) / 1e12
                 traffic, traffic_src = None, None          # HBM bytes per launch from committed rocprofv3 --pmc passes
                 try:
                     with open(os.path.join(ROOT, "profiles", "pmc_conv_latest.json")) as f:
                         traffic_src = json.load(f)
-                    traffic = traffic_src["hbm_bytes_per_launch"] if fused else None
+                    traffic = traffic_src["hbm_bytes_per_launch"] if (fused and not whole and B == 4096) else None
                 except Exception:
                     pass
-                out["roofline"] = {"kernel": "k_block_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU)" if fused
+                out["roofline"] = {"kernel": "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole
+                                   else "k_block16_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU, 16x16x32 MFMA)" if fused
                                    else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
                                    "launch_ms": conv_ms, "algorithmic_flop_per_launch": conv_flop, "sampled_launches": len(conv_events),
