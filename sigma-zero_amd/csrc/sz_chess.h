@@ -499,11 +499,11 @@ SZ_HD u64 sz_aux_plane(const SzPos& leaf, int j /* 0..6 */) {
 // ---------------------------------------------------------------------------------------------
 // start positions
 // ---------------------------------------------------------------------------------------------
-SZ_HD SzPos sz_start_from_backrank(const int* files /* 8 piece codes */, int all_rooks_castle) {
+SZ_HD SzPos sz_start_from_backrank(u64 kn, u64 bi, u64 ro, u64 qu, u64 ki /* file masks, bits 0..7 */, int all_rooks_castle) {
     SzPos p;
-    for (int k = 0; k < 6; k++) p.pc[k] = 0;
-    for (int f = 0; f < 8; f++) p.pc[files[f]] |= sz_bit(f) | sz_bit(56 + f);
+    const u64 both = 0x0100000000000001ULL;                 // file bit on rank 1 and rank 8
     p.pc[SZ_P] = 0x00FF00000000FF00ULL;
+    p.pc[SZ_N] = kn * both; p.pc[SZ_B] = bi * both; p.pc[SZ_R] = ro * both; p.pc[SZ_Q] = qu * both; p.pc[SZ_K] = ki * both;
     p.white = 0x000000000000FFFFULL;
     p.castling = all_rooks_castle ? p.pc[SZ_R] : (sz_bit(0) | sz_bit(7) | sz_bit(56) | sz_bit(63));
     p.meta = ((u64)1 << SZM_TURN_BIT) | ((u64)1 << SZM_IRREV_BIT);
@@ -512,22 +512,25 @@ SZ_HD SzPos sz_start_from_backrank(const int* files /* 8 piece codes */, int all
 }
 // Board.from_chess960_pos(n) (Scharnagl numbering); n < 0 -> chess.Board()
 SZ_HD SzPos sz_startpos(int scharnagl) {
-    int files[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    if (scharnagl < 0) {
-        const int std_[8] = {SZ_R, SZ_N, SZ_B, SZ_Q, SZ_K, SZ_B, SZ_N, SZ_R};
-        return sz_start_from_backrank(std_, 0);
-    }
+    if (scharnagl < 0) return sz_start_from_backrank(0x42, 0x24, 0x81, 0x08, 0x10, 0);   // RNBQKBNR
+    // file occupancy is tracked as an 8-bit mask (no runtime-indexed arrays: they would live in scratch memory on the GPU)
     int n = scharnagl;
-    int bw = n % 4; n /= 4;
-    int bd = n % 4; n /= 4;
-    int q = n % 6; n /= 6;
-    files[bw * 2 + 1] = SZ_B;
-    files[bd * 2] = SZ_B;
-    for (int f = 0, free_i = 0; f < 8; f++) if (files[f] < 0) { if (free_i == q) { files[f] = SZ_Q; break; } free_i++; }
-    // knights: n in 0..9 enumerates the 10 pairs of the 5 free squares in lexicographic order
+    const int bw = n % 4; n /= 4;
+    const int bd = n % 4; n /= 4;
+    const int q = n % 6; n /= 6;
+    u64 bi = sz_bit(bw * 2 + 1) | sz_bit(bd * 2);
+    u64 used = bi;
+    // k-th free file (k counted from the a-file)
+    auto kth_free = [&](int k) -> u64 {
+        u64 freem = ~used & 0xFF;
+        for (int i = 0; i < k; i++) freem &= freem - 1;
+        return freem & (~freem + 1);
+    };
+    const u64 qu = kth_free(q); used |= qu;
+    // knights: n in 0..9 enumerates the 10 pairs of the 5 free files in lexicographic order
     int a = 0, b2 = 1, cnt = n;
     for (a = 0; a < 4; a++) { int span = 4 - a; if (cnt < span) { b2 = a + 1 + cnt; break; } cnt -= span; }
-    for (int f = 0, free_i = 0; f < 8; f++) if (files[f] < 0) { if (free_i == a || free_i == b2) files[f] = SZ_N; free_i++; }
-    for (int f = 0, k = 0; f < 8; f++) if (files[f] < 0) { files[f] = (k == 1) ? SZ_K : SZ_R; k++; }
-    return sz_start_from_backrank(files, 1);
+    const u64 kn = kth_free(a) | kth_free(b2); used |= kn;
+    const u64 r1 = kth_free(0), ki = kth_free(1), r2 = kth_free(2);
+    return sz_start_from_backrank(kn, bi, r1 | r2, qu, ki, 1);
 }

@@ -369,3 +369,57 @@ def test_arena_greedy_match():
     idx, vis, _ = s.root_children()
     assert int(rec["chosen"][0]) == idx[int(np.argmax(vis))]
     eng.close()
+
+
+def test_full_games_to_the_end_match_oracle():
+    """whole self-play games (tiny search budget) until every game is over: move sampling, repetition planes, 75-move /
+    fivefold / insufficient-material / mate detection and results on the device, ply by ply against the oracle"""
+    S, B, MAX_PLIES = 3, 10, 700
+    rng = random.Random(11)
+    sch = [rng.randrange(960) for _ in range(B)]
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=True, learning=True)
+    eng.new_games(sch)
+    octs = [O.ChessTensor(chess960=True, scharnagl=n) for n in sch]
+    alive = [True] * B
+    ev = random_evaluator(123)
+    urng = np.random.RandomState(7)
+    ended = {}
+    for ply in range(MAX_PLIES):
+        searches = [O.Search.on_chess(o, c=2.0, num_searches=S, learning=True, noise_value=NOISE_REFERENCE) if alive[b] else None
+                    for b, o in enumerate(octs)]
+        eng.begin()
+        for step in range(S):
+            policy, value = ev(eng.planes, step)
+            pol_h, val_h = policy.cpu().numpy(), value.cpu().numpy()
+            for b, s in enumerate(searches):
+                if s is not None and s.advance():
+                    s.feed(pol_h[b], val_h[b])
+            eng.step(policy, value)
+        u = urng.random_sample(B)
+        eng.play(u)
+        rec = eng.fetch_ply()
+        eng.check_errors()
+        for b, s in enumerate(searches):
+            if s is None:
+                assert not rec["active"][b]
+                continue
+            assert not s.advance()
+            idx, vis, moves = s.root_children()
+            k = int(rec["n_child"][b])
+            assert rec["action"][b, :k].tolist() == idx and rec["visits"][b, :k].tolist() == vis, (ply, b)
+            assert np.array_equal(unpack_planes(rec["packed"][b]).astype(np.uint8), octs[b].get_representation()), (ply, b)
+            choice = O.sample_move(vis, u[b])
+            assert int(rec["chosen"][b]) == idx[choice], (ply, b)
+            octs[b].move_piece(moves[choice])
+            v, t = octs[b].get_value_and_terminated()
+            assert bool(rec["game_over"][b]) == t, (ply, b)
+            if t:
+                kind, w = octs[b].board.outcome()
+                assert int(rec["result"][b]) == (0 if w < 0 else (1 if w == 1 else -1))
+                ended[b] = kind
+                alive[b] = False
+        if not any(alive):
+            break
+    eng.close()
+    assert len(ended) >= B - 2, "games should finish within %d plies: %s" % (MAX_PLIES, ended)
+    assert len(set(ended.values())) >= 2, ended          # more than one kind of game end was exercised
