@@ -196,3 +196,90 @@ def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync
     ds = SelfPlayDataset(packed, aidx, aprob, rew)
     dl = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, drop_last=True, collate_fn=SelfPlayDataset.collate)
     return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device), games
+
+
+# ----------------------------------------------------------------------------- train_RL.main (:156-275), one process per GPU
+def sync_module_state(model, average_buffers=True):
+    """Rank 0's parameters to every rank (start of training); BatchNorm running statistics averaged over ranks (end of a
+    cycle) so that every rank plays its next self-play cycle with the same inference network."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    for p in model.parameters():
+        dist.broadcast(p.data, src=0)
+    for name, buf in model.named_buffers():
+        if not buf.dtype.is_floating_point:
+            dist.broadcast(buf, src=0)
+        elif average_buffers:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            buf.div_(world)
+        else:
+            dist.broadcast(buf, src=0)
+
+
+def pack_games_for_save(games):
+    """games/RL_960_{epoch}.pt of train_RL.py:241, with states in the (119,8) uint8 bit-packed format and UCI move keys."""
+    packed, aidx, aprob, rew = records_from_games(games)
+    return {"states": [torch.from_numpy(p) for p in packed],
+            "actions": [{m.uci(): float(v) for m, v in act.items()} for g in games for act in g["actions"]],
+            "rewards": rew, "colours": [c for g in games for c in g["colours"]]}
+
+
+def main(argv=None):
+    """`python -m torch.distributed.run --nproc-per-node N -m sigma_zero_amd.train_rl ...` (or plain python for one GPU):
+    every rank self-plays its own games on its own GPU (no communication), then all ranks train with averaged gradients."""
+    import argparse
+    import torch.distributed as dist
+    ap = argparse.ArgumentParser(description="RL loop of train_RL.py on the MI355X engine")
+    ap.add_argument("--epochs", type=int, default=1)                  # train_RL.py:174 num_epochs (cycles)
+    ap.add_argument("--start-epoch", type=int, default=1)             # :175
+    ap.add_argument("--games-per-rank", type=int, default=40)         # :165 num_games, per GPU here
+    ap.add_argument("--searches", type=int, default=100)              # :170
+    ap.add_argument("--batch-size", type=int, default=128)            # :173
+    ap.add_argument("--total-steps", type=int, default=6)             # :261 -> 7 passes
+    ap.add_argument("--chess960", type=int, default=1)                # :176
+    ap.add_argument("--max-plies", type=int, default=100000)
+    ap.add_argument("--init", default=None, help="state_dict to start from (reference checkpoints load: same keys)")
+    ap.add_argument("--save-dir", default="saves")
+    ap.add_argument("--games-dir", default="games")
+    ap.add_argument("--backend", default="nccl")
+    a = ap.parse_args(argv)
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("train_rl needs an MI355X: self-play has no CPU path")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    if world > 1:
+        dist.init_process_group(backend=a.backend)
+    from .network import policyNN
+    torch.manual_seed(0)
+    model = policyNN({}).to(device)
+    if a.init:
+        model.load_state_dict(torch.load(a.init, map_location=device, weights_only=True))
+    sync_module_state(model, average_buffers=False)
+    optimiser, sched = make_optimiser(model)
+    sync = GradSync(model) if world > 1 else None
+    args = {"C": 2, "num_searches": a.searches, "max_plies": a.max_plies}
+    import random
+    random.seed(1000 + rank)
+    np.random.seed(1000 + rank)
+    for epoch in range(a.start_epoch, a.start_epoch + a.epochs):
+        hist, games = run_cycle(model, optimiser, sched, args, a.games_per_rank, chess960=bool(a.chess960), sync=sync,
+                                batch_size=a.batch_size, total_steps=a.total_steps)
+        sync_module_state(model, average_buffers=True) if world > 1 else None
+        n_samples = sum(len(g["actions"]) for g in games)
+        if rank == 0:
+            save_cycle(model, optimiser, epoch, a.save_dir)
+            os.makedirs(a.games_dir, exist_ok=True)
+            torch.save(pack_games_for_save(games), os.path.join(a.games_dir, "RL_960_%d.pt" % epoch))
+            last = hist[-1] if hist else (float("nan"), float("nan"))
+            print("epoch %d: %d ranks x %d games, %d samples on rank 0, %d optimiser steps, last mse %.4f ce %.4f"
+                  % (epoch, world, a.games_per_rank, n_samples, len(hist), last[0], last[1]), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -423,3 +423,22 @@ def test_full_games_to_the_end_match_oracle():
     eng.close()
     assert len(ended) >= B - 2, "games should finish within %d plies: %s" % (MAX_PLIES, ended)
     assert len(set(ended.values())) >= 2, ended          # more than one kind of game end was exercised
+
+
+def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
+    """the train_RL.main loop as two gloo ranks sharing the GPU: per-rank self-play, bucketed gradient all-reduce, rank-0 saves
+    with the reference's file names and state_dict keys"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "tools", "run_train_rl.py"), "--epochs", "1", "--games-per-rank", "6", "--searches", "4", "--batch-size", "8", "--total-steps", "0",
+           "--max-plies", "10", "--backend", "gloo", "--save-dir", str(tmp_path / "saves"), "--games-dir", str(tmp_path / "games")]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "epoch 1: 2 ranks x 6 games" in out.stdout
+    sd = torch.load(tmp_path / "saves" / "RL_1.pt", weights_only=True)
+    assert list(sd.keys()) == list(sz.policyNN({}).state_dict().keys())
+    games = torch.load(tmp_path / "games" / "RL_960_1.pt", weights_only=True)
+    assert len(games["states"]) == len(games["actions"]) == len(games["rewards"]) == len(games["colours"]) > 0
+    assert tuple(games["states"][0].shape) == (119, 8) and games["states"][0].dtype == torch.uint8
