@@ -442,3 +442,33 @@ def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
     games = torch.load(tmp_path / "games" / "RL_960_1.pt", weights_only=True)
     assert len(games["states"]) == len(games["actions"]) == len(games["rewards"]) == len(games["colours"]) > 0
     assert tuple(games["states"][0].shape) == (119, 8) and games["states"][0].dtype == torch.uint8
+
+
+def test_slot_refill_keeps_other_boards_intact():
+    """finished games are replaced by new ones in place (steady-state self-play): only the flagged boards restart"""
+    B, S = 8, 3
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=True, learning=True)
+    sch = [11, 22, 33, 44, 55, 66, 77, 88]
+    eng.new_games(sch)
+    ev = random_evaluator(5)
+    urng = np.random.RandomState(3)
+    for ply in range(6):
+        eng.search(lambda planes: ev(planes, 0))
+        eng.play(urng.random_sample(B))
+        eng.fetch_ply()
+    before = [eng.debug_position(b) for b in range(B)]
+    assert all(p[1] == 6 for p in before)
+    mask = np.array([0, 1, 0, 0, 1, 0, 0, 0], dtype=np.uint8)
+    eng.new_games([900 + b for b in range(B)], active=mask)
+    torch.cuda.synchronize()
+    for b in range(B):
+        pos, gply = eng.debug_position(b)
+        if mask[b]:
+            assert gply == 0 and [int(x) for x in pos[:7]] == O.Board.from_chess960_pos(900 + b).bitboards()[:7]
+        else:
+            assert gply == 6 and np.array_equal(pos, before[b][0])
+    eng.search(lambda planes: ev(planes, 0))
+    eng.check_errors()
+    _, visits, n_child, _, _ = eng.root_children()
+    assert all(visits[b, :n_child[b]].sum() == S - 1 for b in range(B))
+    eng.close()
