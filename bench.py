@@ -244,7 +244,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step_time": tree_ms / (tree_ms + nn_ms)}
             fl = exps / launches * sz.network.FLOPS_PER_BOARD
             tf = fl / (nn_ms * 1e-3) / 1e12
-            nn_roof = {"kernel": "policyNN forward, all kernels (%s)" % ("sz_nn.hip MFMA tower + torch heads" if fast else "MIOpen/ATen, bf16 channels_last"),
+            nn_roof = {"kernel": "policyNN forward, all kernels (%s)" % ("sz_nn.hip MFMA tower + native heads" if fast else "MIOpen/ATen, bf16 channels_last"),
                        "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
                        "forward_ms": nn_ms, "useful_boards_per_forward": exps / launches}
             if fast and conv_events:

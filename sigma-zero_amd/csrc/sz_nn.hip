@@ -24,7 +24,9 @@
 //   * epilogue through LDS: (acc + bias) -> bf16 -> [pos][co] image, then whole 16-byte chunks are moved with
 //     coalesced residual reads and stores (scattered 8-byte stores from the accumulator layout cost 20 %).
 // `flags` bit 0 = ReLU; higher bits are timing-ablation / A-B switches used by tools/conv_bench.py only
-// (2/4/8 skip load/store/K loop, 16 = 4-board workgroups, 32/64 + bits 8..15 = phase stagger, 0x10000 = no stagger).
+// (2/4/8 skip load/store/K loop, 16 = 4-board workgroups, 32/64 + bits 8..15 = phase stagger, 0x10000 = no stagger,
+// 0x200000/0x400000/0x800000 = streaming (non-temporal) tile loads / output stores / residual re-read in the fused block:
+// measured with tools/block_ab.py, all-streaming +3 % slower (the residual re-read then misses), stores or residual alone within noise).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -34,6 +36,18 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// streaming (non-temporal) 16-byte accesses for activation tiles: they are touched once per launch and should not evict
+// the layer's weights (2.4 MB per block, re-read by every workgroup) from the XCD's L2
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+    u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+    u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (u32x4*)p);
+}
 
 #define NN_COUT 256
 #define NN_NI 2                                            // channel tiles (32) per wave
@@ -48,7 +62,7 @@ __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 
 // ---- stage WGB boards' activations (NHWC rows of C_in bf16) into LDS, plus one zero row ---------------------
-template <int CIN, int WGB, int PAD = 16>
+template <int CIN, int WGB, int PAD = 16, bool NT = false>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards, bool skip) {
     constexpr int PITCH = CIN * 2 + PAD;
     constexpr int CHUNKS_PER_POS = CIN / 8;                // 16-B chunks per position
@@ -63,7 +77,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
 #pragma unroll
     for (int i = 0; i < PER_THREAD; i++) {
         const int c = tid + i * 256;
-        stage[i] = (c < valid_chunks && !skip) ? src[c] : make_uint4(0, 0, 0, 0);
+        stage[i] = (c < valid_chunks && !skip) ? (NT ? ld_stream(src + c) : src[c]) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < PER_THREAD; i++) {
@@ -184,7 +198,7 @@ __device__ __forceinline__ void acc_to_lds(unsigned char* lds, const f32x16 (&ac
 
 // ---- LDS image -> (+ residual) -> (ReLU) -> coalesced 16-byte NHWC stores ------------------------------------
 // The residual is added to the bf16-rounded conv+bias value (torch's own bf16 graph rounds there too).
-template <int WGB, int PAD = 16>
+template <int WGB, int PAD = 16, bool NT = false, bool NTS = NT>
 __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int board0, int n_boards, bool relu) {
     constexpr int OPITCH = NN_COUT * 2 + PAD;
     constexpr int OUT_CHUNKS = WGB * 64 * 32;              // 16-byte chunks of the output tile
@@ -198,7 +212,7 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
         uint4 v = *(const uint4*)(lds + (c >> 5) * OPITCH + (c & 31) * 16);
         float f[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
         if (res4) {
-            uint4 r = res4[c];
+            uint4 r = NT ? ld_stream(res4 + c) : res4[c];
             f[0] += bf16_lo(r.x); f[1] += bf16_hi(r.x); f[2] += bf16_lo(r.y); f[3] += bf16_hi(r.y);
             f[4] += bf16_lo(r.z); f[5] += bf16_hi(r.z); f[6] += bf16_lo(r.w); f[7] += bf16_hi(r.w);
         }
@@ -208,7 +222,7 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
         }
         uint4 o;
         o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]); o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
-        out4[c] = o;
+        if (NTS) st_stream(out4 + c, o); else out4[c] = o;
     }
 }
 
@@ -414,7 +428,9 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : (WGB == 1 ? 3 : 1))) void k_bl
                                                          int n_boards, int flags, int n_cu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int board0 = blockIdx.x * WGB;
-    stage_tile<256, WGB, NN_PAD16>(lds, in, board0, n_boards, false);
+    const bool nt = (flags & 0x200000) != 0;               // A/B: streaming tile loads/stores
+    if (nt) stage_tile<256, WGB, NN_PAD16, true>(lds, in, board0, n_boards, false);
+    else stage_tile<256, WGB, NN_PAD16>(lds, in, board0, n_boards, false);
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
@@ -426,7 +442,11 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : (WGB == 1 ? 3 : 1))) void k_bl
     __syncthreads();
     acc_to_lds16<WGB>(lds, acc, b2, false);
     __syncthreads();
-    lds_to_out<WGB, NN_PAD16>(lds, in, out, board0, n_boards, true);
+    if (nt) lds_to_out<WGB, NN_PAD16, true>(lds, in, out, board0, n_boards, true);
+    else if ((flags & 0xC00000) == 0xC00000) lds_to_out<WGB, NN_PAD16, true, true>(lds, in, out, board0, n_boards, true);
+    else if (flags & 0x400000) lds_to_out<WGB, NN_PAD16, false, true>(lds, in, out, board0, n_boards, true);    // A/B: streaming stores only
+    else if (flags & 0x800000) lds_to_out<WGB, NN_PAD16, true, false>(lds, in, out, board0, n_boards, true);    // A/B: streaming residual re-read only
+    else lds_to_out<WGB, NN_PAD16>(lds, in, out, board0, n_boards, true);
 }
 
 // =================================================================================================================
