@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--net", default="fast", choices=["fast", "torch"],
                     help="fast: hand-written MFMA conv tower (csrc/sz_nn.hip); torch: MIOpen/ATen kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path on one GPU)")
+    ap.add_argument("--planes", default="bits128", choices=["bits128", "nhwc128"],
+                    help="network-input image written by the tree kernel on the fast path: bit-packed (1 KiB/board) or bf16 NHWC (16 KiB/board)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
@@ -143,7 +145,7 @@ def main():
     if fast:
         from sigma_zero_amd.fastnet import FastPolicyNet
         model = FastPolicyNet(sz.policyNN({}).eval(), device=dev)
-        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype="nhwc128")
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=a.planes)
     else:
         model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
         eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype)
@@ -229,14 +231,15 @@ def main():
             nn_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_nn]))
             launches = len(ev_tree)
             # network-input bytes per board: NCHW 119x64 elements, or the NHWC image of 64 x 128 bf16 on the fast path
-            plane_bytes = (128.0 * 2 / 119) if fast else (2 if dtype == torch.bfloat16 else 4)
+            # network-input bytes per plane cell: bit-packed image 1024 B / (119*64), bf16 NHWC image 16 KiB / (119*64), NCHW 2 or 4
+            plane_bytes = ((1024.0 / (119 * 64)) if a.planes == "bits128" else (128.0 * 2 / 119)) if fast else (2 if dtype == torch.bfloat16 else 4)
             bytes_per_launch = tree_bytes_per_launch(B, sims, exps, sum_depth, sum_k, plane_bytes) / launches
             ach = bytes_per_launch / (tree_ms * 1e-3) / 1e9
             tree_traffic, tree_src = None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_tree_latest.json")) as f:
                     tree_src = json.load(f)
-                tree_traffic = tree_src["hbm_bytes_per_launch"] if (fast and B == 4096) else None
+                tree_traffic = tree_src["hbm_bytes_per_launch"] if (fast and B == 4096 and tree_src.get("planes") == a.planes) else None
             except Exception:
                 pass
             tree_roof = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

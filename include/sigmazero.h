@@ -36,8 +36,11 @@ enum {
 
 /* network-input layouts written by the engine:
  *   F32 / BF16     : [n_boards,119,8,8] NCHW, the reference's get_representation() layout
- *   NHWC128_BF16   : [n_boards,64,128] position-major, channels 119..127 zero — input of sz_nn_conv_bf16 (stem) */
-enum { SZ_PLANES_F32 = 0, SZ_PLANES_BF16 = 1, SZ_PLANES_NHWC128_BF16 = 2 };
+ *   NHWC128_BF16   : [n_boards,64,128] position-major, channels 119..127 zero — input of sz_nn_conv_bf16 (stem)
+ *   NHWC128_BITS   : the same image bit-packed, 1 KiB per board (16x fewer bytes than bf16): [n_boards][64 lanes] uint4,
+ *                    lane l = psub*16 + cq; byte q (little-endian) of its 16 bytes holds channels cq*8..cq*8+7 (bit k =
+ *                    channel cq*8+k) of position q*4 + psub.  Consumed by the stem with SZ_NN_IN_BITS. */
+enum { SZ_PLANES_F32 = 0, SZ_PLANES_BF16 = 1, SZ_PLANES_NHWC128_BF16 = 2, SZ_PLANES_NHWC128_BITS = 3 };
 
 /* ------------------------------------------------------------------ engine (HIP, gfx950) */
 
@@ -138,6 +141,8 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
 /* flag for `relu`/`flags` of the two entry points below: the weights were packed by sz_nn_pack_weights16 and the
  * 16x16x32 MFMA kernels are used (same results; the chip holds a higher clock on that shape) */
 #define SZ_NN_W16 0x40000
+/* flag for the stem (cin 128, ksize 3, SZ_NN_W16) and for sz_nn_tower_bf16: `in` is the engine's SZ_PLANES_NHWC128_BITS image */
+#define SZ_NN_IN_BITS 0x1000000
 /* One whole BasicBlock (network.py:36-83) in one launch: out = relu(conv3x3(relu(conv3x3(in,w1)+b1),w2)+b2+in); the
  * intermediate activation stays in LDS.  in/out [n_boards,64,256] bf16 NHWC, out != in. */
 int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* out,
@@ -149,10 +154,10 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
 
 /* The whole tower (network.py:176-184: stem conv + n_blocks BasicBlocks) in ONE persistent launch: a workgroup keeps its
  * boards' activations in LDS through all 1 + 2*n_blocks convolutions; only weights stream.  planes [n_boards,64,128] bf16
- * (SZ_PLANES_NHWC128_BF16), out [n_boards,64,256] bf16; w_packed / bias: HOST arrays of 1 + 2*n_blocks DEVICE pointers
+ * (SZ_PLANES_NHWC128_BF16; or _BITS with SZ_NN_IN_BITS), out [n_boards,64,256] bf16; w_packed / bias: HOST arrays of 1 + 2*n_blocks DEVICE pointers
  * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128). */
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
-                     int32_t n_boards, void* stream);
+                     int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
 /* Heads of policyNN (network.py:141-174) as two small kernels:
  *  policy: t = relu(bn(conv_p1(x))) [n_boards,64,256] bf16 -> conv_p2 + bias -> (softmax) -> probs [n_boards,4672] f32 in the
  *          reference's flatten order (plane*64 + row*8 + col); w_packed from sz_nn_pack_head16(conv_p2.weight [73,256]);
@@ -161,6 +166,12 @@ int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bia
 int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
                           float* value, int32_t n_boards, void* stream);
 int sz_nn_pack_head16(const float* w_in, uint16_t* out);
+/* Both heads from ONE read of the tower output x (replaces sz_nn_conv_bf16(ksize 1) + the two calls above): conv_p1 -> LDS -> conv_p2 ->
+ * softmax -> probs, and conv_v1 -> value MLP -> value.  w_p1_packed: conv_p1 with p_norm1 folded, sz_nn_pack_weights16(cin_padded 256,
+ * ksize 1); v1_scratch: [n_boards*64] f32 device scratch (conv_v1 outputs between the two internal launches). */
+int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, const void* w_p2_packed, const float* b_p2, const float* wv, float bv,
+                     const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch,
+                     int32_t n_boards, int32_t do_softmax, void* stream);
 
 const char* sz_error_string(int code);
 int sz_device_count(void);

@@ -7,8 +7,9 @@ from . import build as _build
 
 SZ_RING, SZ_PLANES, SZ_ACTIONS, SZ_MAX_MOVES, SZ_POS_BYTES, SZ_MASK_WORDS = 256, 119, 4672, 218, 80, 73
 SZ_OK, SZ_ERR_INVALID, SZ_ERR_HIP, SZ_ERR_CAPACITY, SZ_ERR_NO_DEVICE, SZ_ERR_STATE, SZ_ERR_ZERO_VISITS = 0, -1, -2, -3, -4, -5, -6
-SZ_PLANES_F32, SZ_PLANES_BF16, SZ_PLANES_NHWC128_BF16 = 0, 1, 2
+SZ_PLANES_F32, SZ_PLANES_BF16, SZ_PLANES_NHWC128_BF16, SZ_PLANES_NHWC128_BITS = 0, 1, 2, 3
 SZ_NN_W16 = 0x40000
+SZ_NN_IN_BITS = 0x1000000
 
 
 class sz_config(C.Structure):
@@ -47,8 +48,9 @@ EXPORTS = {
     "sz_debug_position": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "sz_nn_conv_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
-    "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_policy_head_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_void_p]),
+    "sz_nn_heads_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_value_head_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "sz_nn_pack_head16": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sz_nn_pack_weights16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

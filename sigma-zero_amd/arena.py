@@ -12,7 +12,7 @@ def play_match(model_a, model_b, args, n_games, chess960=False, scharnagl=None, 
     """Returns {'a_wins', 'b_wins', 'draws', 'unfinished', 'results'}; model_a has white on even boards, black on odd ones."""
     import random
     if planes_dtype is None:
-        planes_dtype = "nhwc128" if hasattr(model_a, "tower") else torch.float32
+        planes_dtype = ("bits128" if getattr(model_a, "w16", False) and getattr(model_b, "w16", False) else "nhwc128") if hasattr(model_a, "tower") else torch.float32
     eng = SelfPlayEngine(None, args, n_games, chess960=chess960, learning=False, device=device, planes_dtype=planes_dtype)
     if chess960 and scharnagl is None:
         scharnagl = [random.randint(0, 959) for _ in range(n_games)]

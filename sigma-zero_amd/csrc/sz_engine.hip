@@ -79,7 +79,8 @@ __device__ __forceinline__ float wave_sum_butterfly(float v) {
     return v;
 }
 __device__ __forceinline__ size_t planes_board_bytes(int dtype) {
-    return dtype == SZ_PLANES_F32 ? (size_t)SZ_NUM_PLANES * 64 * 4 : (dtype == SZ_PLANES_BF16 ? (size_t)SZ_NUM_PLANES * 64 * 2 : (size_t)64 * 128 * 2);
+    return dtype == SZ_PLANES_F32 ? (size_t)SZ_NUM_PLANES * 64 * 4 : (dtype == SZ_PLANES_BF16 ? (size_t)SZ_NUM_PLANES * 64 * 2 :
+           (dtype == SZ_PLANES_NHWC128_BITS ? (size_t)1024 : (size_t)64 * 128 * 2));
 }
 // lane-indexed ballot (bit v = view square v) -> real-square bitboard
 __device__ __forceinline__ u64 view_to_squares(u64 m, int white) {
@@ -197,6 +198,30 @@ __device__ void wave_load_history(const BoardPtrs& bp, const int* path, int D, i
 __device__ void wave_encode(const u64* hist_lds, const SzPos& X, void* out_board, int dtype, uint8_t* packed_out) {
     const int lane = lane_id();
     const int vw = szm_turn(X.meta);
+    if (dtype == SZ_PLANES_NHWC128_BITS && out_board) {
+        // bit-packed NHWC image, 1 KiB per board = ONE 16-byte store per lane: lane l = psub*16 + cq owns channels
+        // cq*8..cq*8+7; byte q of its uint4 = those 8 channel bits at position q*4 + psub (view order).  The stem
+        // kernel (csrc/sz_nn.hip stage_tile_bits) expands the bits to bf16 while staging its LDS tile.
+        const int cq = lane & 15, psub = lane >> 4;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = cq * 8 + k;
+            u64 bb = (c < 112) ? sz_hist_plane(hist_lds + (c / 14) * 8, c % 14, vw) : (c < SZ_NUM_PLANES ? sz_aux_plane(X, c - 112) : 0ULL);
+            // view position p <-> board square p ^ sz_view_flip: ^56 (white) = byte swap, ^7 (black) = bit reversal + byte swap
+            bb = __builtin_bswap64(vw ? bb : __brevll(bb));
+            bb >>= psub;
+            const uint32_t lo = (uint32_t)bb, hi = (uint32_t)(bb >> 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                w[q >> 2] |= ((lo >> (4 * q)) & 1u) << ((q & 3) * 8 + k);
+                w[2 + (q >> 2)] |= ((hi >> (4 * q)) & 1u) << ((q & 3) * 8 + k);
+            }
+        }
+        ((uint4*)out_board)[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (!packed_out) return;
+        out_board = nullptr;
+    }
     if (dtype == SZ_PLANES_NHWC128_BF16 && out_board) {
         // NHWC image [64 positions][128 channels] bf16 = 16 KB = 16 wave-instructions of 1 KiB, each fully contiguous:
         // in store q lane l covers position q*4 + (l>>4), channels (l&15)*8 .. +7.  A lane's 8 channel bitboards do not

@@ -87,6 +87,32 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
     for (int c = tid; c < PITCH / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
 }
 
+// ---- stage WGB boards from the engine's bit-packed planes (SZ_PLANES_NHWC128_BITS: 1 KiB per board) ----------
+// uint4 l of a board (l = psub*16 + cq): byte q = channels cq*8..cq*8+7 of position q*4 + psub.  Two threads share a
+// uint4 (q 0..7 / 8..15); each expands 8 bytes to 8 chunks of 8 bf16 (1.0 = 0x3F80) and writes them to its LDS rows.
+template <int WGB, int PAD>
+__device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards) {
+    constexpr int PITCH = 128 * 2 + PAD;
+    const uint4* src = (const uint4*)in + (size_t)board0 * 64;
+    for (int t = threadIdx.x; t < WGB * 128; t += 256) {
+        const int board = t >> 7, half = (t >> 6) & 1, l = t & 63, psub = l >> 4, cq = l & 15;
+        uint4 v = (board0 + board < n_boards) ? src[board * 64 + l] : make_uint4(0, 0, 0, 0);
+        const uint32_t w0 = half ? v.z : v.x, w1 = half ? v.w : v.y;
+#pragma unroll
+        for (int qq = 0; qq < 8; qq++) {
+            const uint32_t byte = ((qq < 4 ? w0 : w1) >> ((qq & 3) * 8)) & 0xFFu;
+            uint4 o;
+            o.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
+            o.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
+            o.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
+            o.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+            const int pos = (half * 8 + qq) * 4 + psub;
+            *(uint4*)(lds + (board * 64 + pos) * PITCH + cq * 16) = o;
+        }
+    }
+    for (int c = threadIdx.x; c < PITCH / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+}
+
 // ---- the K loop: acc[i][j] += W[tap,k] x Act[tap,k]^T over all taps and channels ----------------------------
 // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches to their uses:
 //   issue { weights of k-step ks+PF (L2 -> ring), activations of ks+1 (LDS -> bfrag) } ; NI*NJ MFMAs of ks.
@@ -411,7 +437,8 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
                                                         const uint16_t* __restrict__ res, uint16_t* __restrict__ out, int n_boards, int flags, int n_cu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int board0 = blockIdx.x * WGB;
-    stage_tile<CIN, WGB, NN_PAD16>(lds, in, board0, n_boards, (flags & 2) != 0);
+    if (CIN == 128 && (flags & SZ_NN_IN_BITS)) stage_tile_bits<WGB, NN_PAD16>(lds, in, board0, n_boards);
+    else stage_tile<CIN, WGB, NN_PAD16>(lds, in, board0, n_boards, (flags & 2) != 0);
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
@@ -527,7 +554,8 @@ __global__ __launch_bounds__(256) void k_policy_head(const uint16_t* __restrict_
 
 #define VH_BOARDS_PER_WAVE 4
 __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__ x, const float* __restrict__ wv, float bv, const float* __restrict__ fc1_w /*[64][256]*/,
-                                                     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float fc2_b, float* __restrict__ value, int n_boards) {
+                                                     const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float fc2_b, float* __restrict__ value, int n_boards,
+                                                     const float* __restrict__ v1_in /* optional: relu(bn(conv_v1)) [n_boards][64] from k_heads16_bf16 */) {
     // workgroup = 4 waves x 4 boards each; fc_v1's 64 KB weight matrix is staged in LDS once per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char vh_lds[];
     float* w1s = (float*)vh_lds;                            // [64][256]
@@ -536,7 +564,7 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
     for (int c = threadIdx.x; c < 64 * 256 / 4; c += 256) ((float4*)w1s)[c] = ((const float4*)fc1_w)[c];
     float wreg[8], b1r[4], w2r[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) wreg[k] = wv[(lane & 31) * 8 + k];
+    for (int k = 0; k < 8; k++) wreg[k] = v1_in ? 0.f : wv[(lane & 31) * 8 + k];
 #pragma unroll
     for (int q = 0; q < 4; q++) { b1r[q] = fc1_b[lane + 64 * q]; w2r[q] = fc2_w[lane + 64 * q]; }
     __syncthreads();
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
         const uint4* tile = (const uint4*)(x + (size_t)board * 64 * 256);
         float dot = 0.f;                                    // lane p ends up with the conv_v1 output of position p
 #pragma unroll 8
-        for (int i = 0; i < 32; i++) {
+        for (int i = 0; i < (v1_in ? 0 : 32); i++) {
             uint4 v = tile[i * 64 + lane];
             float part = bf16_lo(v.x) * wreg[0] + bf16_hi(v.x) * wreg[1] + bf16_lo(v.y) * wreg[2] + bf16_hi(v.y) * wreg[3] +
                          bf16_lo(v.z) * wreg[4] + bf16_hi(v.z) * wreg[5] + bf16_lo(v.w) * wreg[6] + bf16_hi(v.w) * wreg[7];
@@ -557,7 +585,7 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
             if (lane == 2 * i) dot = lo;
             if (lane == 2 * i + 1) dot = hi;
         }
-        v1s[wave * 64 + lane] = fmaxf(dot + bv, 0.f);       // relu(bn(conv_v1)) for position `lane`
+        v1s[wave * 64 + lane] = v1_in ? v1_in[(size_t)board * 64 + lane] : fmaxf(dot + bv, 0.f);       // relu(bn(conv_v1)) for position `lane`
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the wave's own LDS writes have landed
         float h[4] = {b1r[0], b1r[1], b1r[2], b1r[3]};
@@ -571,6 +599,120 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
         for (int q = 0; q < 4; q++) part += fmaxf(h[q], 0.f) * w2r[q];
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) value[board] = tanhf(part + fc2_b);
+    }
+}
+
+// Both heads from ONE pass over the tower output x (network.py:141-174): the workgroup stages its 2 boards of x in LDS once, then
+//   value : conv_v1 (256 -> 1, v_norm folded, f32 weights) + ReLU per position -> v1_out [n_boards][64] (the 64->256->1 MLP is k_value_head)
+//   policy: t = relu(bn(conv_p1(x)))  (1x1, the tower's own K loop)  -> bf16 into LDS over x -> conv_p2 (256 -> 73) + bias -> softmax over
+//           the board's 4672 logits -> probs f32 in the reference's flatten order [plane*64 + pos].
+// Replaces k_conv16<256,1> + k_policy_head + the x-reading part of k_value_head: x is read once (134 MB at B = 4096) instead of
+// three passes over 134 MB plus a 134 MB intermediate written and re-read.
+__global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restrict__ x, const uint4* __restrict__ w_p1, const float* __restrict__ b_p1,
+                                                          const uint4* __restrict__ w_p2, const float* __restrict__ b_p2, const float* __restrict__ wv, float bv,
+                                                          float* __restrict__ probs, float* __restrict__ v1_out, int n_boards, int do_softmax) {
+    constexpr int WGB = 2, PITCH = NN_COUT * 2 + NN_PAD16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* red = (float*)(lds + (WGB * 64 + 1) * PITCH);    // [4 waves][2]: softmax max / sum exchange between the two waves of a board
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;
+    const int board0 = blockIdx.x * WGB;
+    stage_tile<256, WGB, NN_PAD16>(lds, x, board0, n_boards, false);
+    const float4 wv4 = ((const float4*)wv)[lane];          // conv_v1 weights of channels 4*lane .. 4*lane+3
+    __syncthreads();
+    {   // value conv: wave w owns rows 32w .. 32w+31 (row = board*64 + position).  Every lane forms its 4-channel partial of all 32
+        // rows, then a halving butterfly (16+8+4+2+1+1 = 32 shuffles instead of 32 x 6) leaves row l>>1 in lane l.
+        float part[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const uint2 v = *(const uint2*)(lds + (wave * 32 + r) * PITCH + lane * 8);
+            part[r] = bf16_lo(v.x) * wv4.x + bf16_hi(v.x) * wv4.y + bf16_lo(v.y) * wv4.z + bf16_hi(v.y) * wv4.w;
+        }
+#pragma unroll
+        for (int m = 32, n = 16; m >= 2; m >>= 1, n >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int k = 0; k < n; k++) {
+                const float mine = up ? part[n + k] : part[k], send = up ? part[k] : part[n + k];
+                part[k] = mine + __shfl_xor(send, m);
+            }
+        }
+        const float tot = part[0] + __shfl_xor(part[0], 1);
+        const int row = wave * 32 + (lane >> 1), board = board0 + (row >> 6);
+        if (!(lane & 1) && board < n_boards) v1_out[(size_t)board * 64 + (row & 63)] = fmaxf(tot + bv, 0.f);
+    }
+    f32x4 acc[4][4 * WGB];
+    conv_kloop16<256, 1, WGB>(lds, w_p1, acc, false);
+    __syncthreads();
+    acc_to_lds16<WGB>(lds, acc, b_p1, true);               // t over x, in the layout the MFMA B operand is read from
+    __syncthreads();
+    // policy logits: wave -> board wave>>1, position tiles 2*(wave&1) + {0,1}; 5 channel tiles (73 padded to 80), K = 256
+    const int pboard = wave >> 1, j0 = (wave & 1) * 2;
+    f32x4 pa[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { pa[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pa[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+    for (int kc = 0; kc < 8; kc++) {
+        bf16x8 a[5], b[2];
+#pragma unroll
+        for (int i = 0; i < 5; i++) a[i] = __builtin_bit_cast(bf16x8, w_p2[(size_t)(kc * 5 + i) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[j] = *(const bf16x8*)(lds + (pboard * 64 + (j0 + j) * 16 + p16) * PITCH + kc * 64 + kg * 16);
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) pa[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], pa[i][j], 0, 0, 0);
+    }
+    // lane holds logits of positions (j0+j)*16 + p16, channels i*16 + 4*kg + r
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int co = i * 16 + 4 * kg + r;
+            const float bb = co < 73 ? b_p2[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                pa[i][j][r] += bb;
+                if (co < 73) mx = fmaxf(mx, pa[i][j][r]);
+            }
+        }
+    float inv = 1.0f;
+    if (do_softmax) {                                       // uniform across the workgroup
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) red[wave * 2] = mx;
+        __syncthreads();
+        mx = fmaxf(red[wave * 2], red[(wave ^ 1) * 2]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = i * 16 + 4 * kg + r;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float e = co < 73 ? __expf(pa[i][j][r] - mx) : 0.f;
+                    pa[i][j][r] = e;
+                    sum += e;
+                }
+            }
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) red[wave * 2 + 1] = sum;
+        __syncthreads();
+        inv = 1.0f / (red[(wave & 2) * 2 + 1] + red[((wave & 2) + 1) * 2 + 1]);      // same operand order in both waves of a board
+    }
+    if (board0 + pboard < n_boards) {
+        float* pb = probs + (size_t)(board0 + pboard) * 4672;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = i * 16 + 4 * kg + r;
+                if (co < 73) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) pb[co * 64 + (j0 + j) * 16 + p16] = pa[i][j][r] * inv;
+                }
+            }
     }
 }
 
@@ -612,7 +754,7 @@ struct TowerParams {
     const float* b[NN_MAX_CONVS];
 };
 
-__global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks) {
+__global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags) {
     constexpr int WGB = 2;
     constexpr int IMG = (WGB * 64 + 1) * (NN_COUT * 2 + NN_PAD16);       // one activation image incl. its zero row
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -630,7 +772,8 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         const int board0 = tile * WGB;
         conv_prefetch16<4>(prm.w[0], ring);
         __syncthreads();                                               // previous tile's output image fully read
-        stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(bufT, planes, board0, n_boards);
+        else stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
         __syncthreads();
         conv_kloop16<128, 9, WGB, 4, true>(bufT, prm.w[0], acc, false, false, ring);     // stem: x = relu(bn(conv1(planes)))
         if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
@@ -727,11 +870,12 @@ extern "C" {
 
 // Fused conv (+folded BN) + bias (+ residual) (+ ReLU), NHWC bf16, C_out = 256.
 //   ksize 3: 3x3 pad 1 (network.py:17-29 conv3x3) ; ksize 1: 1x1 (network.py:32-34 conv1x1)
-//   cin: 128 (stem, channels >= 119 are zero) or 256.
+//   cin: 128 (stem, channels >= 119 are zero; with SZ_NN_W16 | SZ_NN_IN_BITS `in` is the bit-packed plane image) or 256.
 int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
                     int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream) {
     if (!in || !w_packed || !bias || !out || n_boards <= 0) return SZ_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if ((relu & SZ_NN_IN_BITS) && !((relu & SZ_NN_W16) && ksize == 3 && cin == 128)) return SZ_ERR_INVALID;
     if (relu & SZ_NN_W16) {                                // weights packed for the 16x16x32 path (sz_nn_pack_weights16)
         if (ksize == 3 && cin == 256) return launch_conv16<256, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
         if (ksize == 3 && cin == 128) return launch_conv16<128, 9>(in, w_packed, bias, residual, out, n_boards, relu, s);
@@ -778,7 +922,7 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
 // Whole tower (stem + n_blocks BasicBlocks) in one persistent launch.  planes [n_boards,64,128] bf16 (NHWC, 119 real channels),
 // out [n_boards,64,256] bf16.  w/b: n_convs = 1 + 2*n_blocks device pointers each (weights from sz_nn_pack_weights16, stem with
 // cin_padded 128; biases [256] f32 with BatchNorm folded), given as HOST arrays of device pointers.
-int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out, int32_t n_boards, void* stream) {
+int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out, int32_t n_boards, int32_t flags, void* stream) {
     if (!planes || !w_packed || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS) return SZ_ERR_INVALID;
     TowerParams prm;
     memset(&prm, 0, sizeof prm);
@@ -793,7 +937,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         attr_set = true;
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
-    hipLaunchKernelGGL(k_tower16_bf16, dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks);
+    hipLaunchKernelGGL(k_tower16_bf16, dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
@@ -818,7 +962,29 @@ int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float*
         attr_set = true;
     }
     const int per_wg = 4 * VH_BOARDS_PER_WAVE;
-    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards);
+    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards, (const float*)nullptr);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+// Both heads from ONE read of the tower output (see k_heads16_bf16).  w_p1_packed: conv_p1 + p_norm1 folded, sz_nn_pack_weights16
+// (cin_padded 256, ksize 1); w_p2_packed: sz_nn_pack_head16; v1_scratch: [n_boards*64] f32 device scratch.
+int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, const void* w_p2_packed, const float* b_p2, const float* wv, float bv,
+                     const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch,
+                     int32_t n_boards, int32_t do_softmax, void* stream) {
+    if (!x || !w_p1_packed || !b_p1 || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0) return SZ_ERR_INVALID;
+    const size_t lds_h = (size_t)(2 * 64 + 1) * (256 * 2 + NN_PAD16) + 64, lds_v = (64 * 256 + 4 * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_heads16_bf16, dim3((n_boards + 1) / 2), dim3(256), lds_h, (hipStream_t)stream, (const uint16_t*)x, (const uint4*)w_p1_packed, b_p1,
+                       (const uint4*)w_p2_packed, b_p2, wv, bv, probs, v1_scratch, n_boards, do_softmax);
+    HIPCHK(hipGetLastError());
+    const int per_wg = 4 * VH_BOARDS_PER_WAVE;
+    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b,
+                       value, n_boards, (const float*)v1_scratch);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

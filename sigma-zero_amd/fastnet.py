@@ -3,7 +3,8 @@
 BatchNorm (eval mode) is folded into the convolution weights and a per-channel bias; every tower layer is ONE
 launch of `sz_nn_conv_bf16` (conv + bias + optional residual + ReLU, NHWC bf16, f32 accumulate).  The 39 tower
 convolutions and conv_p1 run on the custom kernel; the two tiny heads (256->73 1x1, value MLP) stay in torch.
-Input: the engine's NHWC planes [B, 64, 128] bf16 (119 real channels, the rest zero).
+Input: the engine's NHWC planes [B, 64, 128] bf16 (119 real channels, the rest zero), or the same image bit-packed
+([B, 1024] uint8, engine planes_dtype="bits128"), which the stem kernel expands while staging its LDS tile.
 """
 import ctypes as C
 
@@ -74,6 +75,7 @@ class FastPolicyNet:
         self.fc2_w_vec = self.fc2_w.view(256).contiguous()
         self.fc2_b_f = float(self.fc2_b.view(-1)[0])
         self.native_heads = True
+        self.fused_heads = self.w16          # one pass over the tower output for both heads (sz_nn_heads_bf16)
         # whole-tower persistent kernel (sz_nn_tower_bf16): host arrays of device pointers, 16x16x32 weight order only
         self.persistent_tower = self.w16
         self.persistent_max_boards = 1024     # measured: one launch for the whole tower wins at small batches, per-block launches at 4096
@@ -117,18 +119,21 @@ class FastPolicyNet:
         """planes [B,64,128] bf16 NHWC -> tower output [B,64,256] bf16 NHWC"""
         B = planes.shape[0]
         a, t, c = self._buffers(B)[:3]
+        in_bits = N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0      # engine planes_dtype="bits128" (1 KiB per board)
+        if in_bits and not self.w16:
+            raise ValueError("bit-packed planes need the 16x16x32 kernels (mfma16=True)")
         if self.persistent_tower and (B <= self.persistent_max_boards):
             ev = None
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B,
+            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B, in_bits,
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_bf16")
             if ev is not None:
                 ev[1].record()
                 self.timing.append(ev)
             return a, t
-        self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3)
+        self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3, relu=1 | in_bits)
         for (w1, b1, w2, b2) in self.blocks:
             if self.fuse_blocks:
                 self._block(a, w1, b1, w2, b2, c, B)
@@ -154,19 +159,27 @@ class FastPolicyNet:
     def __call__(self, planes, inference=True):
         B = planes.shape[0]
         x, scratch = self.tower(planes)
-        self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
         if self.native_heads:
-            if B not in self._bufs or len(self._bufs[B]) < 5:
+            if B not in self._bufs or len(self._bufs[B]) < 6:
                 self._bufs[B] = self._bufs[B][:3] + [torch.empty(B, 4672, dtype=torch.float32, device=self.device),
-                                                     torch.empty(B, dtype=torch.float32, device=self.device)]
-            policy, value = self._bufs[B][3], self._bufs[B][4]
+                                                     torch.empty(B, dtype=torch.float32, device=self.device),
+                                                     torch.empty(B, 64, dtype=torch.float32, device=self.device)]
+            policy, value, v1 = self._bufs[B][3], self._bufs[B][4], self._bufs[B][5]
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            if self.fused_heads and self.w16:
+                P = lambda t: C.c_void_p(t.data_ptr())
+                N.check(N.lib().sz_nn_heads_bf16(P(x), P(self.p1[0]), P(self.p1[1]), P(self.wp2_packed), P(self.bp2), P(self.wv_f32), self.bv_f,
+                                                 P(self.fc1_w), P(self.fc1_b), P(self.fc2_w_vec), self.fc2_b_f, P(policy), P(value), P(v1),
+                                                 B, int(bool(inference)), st), "sz_nn_heads_bf16")
+                return policy, value.view(B, 1)
+            self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
             N.check(N.lib().sz_nn_policy_head_bf16(C.c_void_p(scratch.data_ptr()), C.c_void_p(self.wp2_packed.data_ptr()), C.c_void_p(self.bp2.data_ptr()),
                                                    C.c_void_p(policy.data_ptr()), B, int(bool(inference)), st), "sz_nn_policy_head_bf16")
             N.check(N.lib().sz_nn_value_head_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(self.wv_f32.data_ptr()), self.bv_f, C.c_void_p(self.fc1_w.data_ptr()),
                                                   C.c_void_p(self.fc1_b.data_ptr()), C.c_void_p(self.fc2_w_vec.data_ptr()), self.fc2_b_f,
                                                   C.c_void_p(value.data_ptr()), B, st), "sz_nn_value_head_bf16")
             return policy, value.view(B, 1)
+        self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
         logits = torch.matmul(scratch.view(B * 64, 256), self.wp2).float().view(B, 64, 73) + self.bp2        # [B,pos,plane]
         logits = logits.transpose(1, 2).reshape(B, 73 * 64)                                                  # flatten of [73,8,8]
         policy = torch.softmax(logits, dim=1) if inference else logits

@@ -29,15 +29,19 @@ class SelfPlayEngine:
         self.planes_dtype = planes_dtype
         # planes_dtype: torch.float32 / torch.bfloat16 -> [B,119,8,8] NCHW (reference layout);
         #               "nhwc128" -> [B,64,128] bf16 position-major for FastPolicyNet (csrc/sz_nn.hip)
+        #               "bits128" -> the same image bit-packed, [B,1024] uint8 (1 KiB per board), expanded by the stem kernel
         self.nhwc = planes_dtype == "nhwc128"
-        code = N.SZ_PLANES_NHWC128_BF16 if self.nhwc else (N.SZ_PLANES_BF16 if planes_dtype == torch.bfloat16 else N.SZ_PLANES_F32)
+        self.bits = planes_dtype == "bits128"
+        code = N.SZ_PLANES_NHWC128_BITS if self.bits else N.SZ_PLANES_NHWC128_BF16 if self.nhwc else (N.SZ_PLANES_BF16 if planes_dtype == torch.bfloat16 else N.SZ_PLANES_F32)
         cfg = N.sz_config(self.B, self.S, float(args["C"]), int(bool(learning)), float(noise_value), int(self.chess960),
                           int(edges_per_board), code, self.device.index or 0)
         self._e = C.c_void_p()
         torch.cuda.set_device(self.device)
         N.check(N.lib().sz_create(C.byref(cfg), C.byref(self._e)), "sz_create")
         dev = self.device
-        if self.nhwc:
+        if self.bits:
+            self.planes = torch.zeros(self.B, 1024, dtype=torch.uint8, device=dev)
+        elif self.nhwc:
             self.planes = torch.zeros(self.B, 64, 128, dtype=torch.bfloat16, device=dev)
         else:
             self.planes = torch.zeros(self.B, N.SZ_PLANES, 8, 8, dtype=planes_dtype, device=dev)
@@ -144,6 +148,15 @@ class SelfPlayEngine:
         ply = C.c_int32()
         N.check(N.lib().sz_debug_position(self._e, int(board), pos.ctypes.data_as(C.c_void_p), C.byref(ply), self._stream()), "sz_debug_position")
         return pos, ply.value
+
+
+def unpack_bits128(planes):
+    """[B,1024] uint8 (SZ_PLANES_NHWC128_BITS) -> [B,64,128] bf16 NHWC image (tests / inspection)."""
+    B = planes.shape[0]
+    v = planes.view(B, 4, 16, 16)                                   # [psub][cq][q] bytes
+    bits = (v.unsqueeze(-1) >> torch.arange(8, device=planes.device, dtype=torch.uint8)) & 1      # [B,psub,cq,q,k]
+    img = bits.permute(0, 3, 1, 2, 4).reshape(B, 64, 128)           # position = q*4 + psub, channel = cq*8 + k
+    return img.to(torch.bfloat16)
 
 
 def unpack_planes(packed):

@@ -36,7 +36,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     model = model.to(device)
     if planes_dtype is None:
         if hasattr(model, "tower"):                       # FastPolicyNet: hand-written MFMA tower, NHWC planes
-            planes_dtype = "nhwc128"
+            planes_dtype = "bits128" if getattr(model, "w16", False) else "nhwc128"     # bit-packed: 1 KiB per board instead of 16
         else:
             planes_dtype = next(model.parameters()).dtype
             if planes_dtype not in (torch.float32, torch.bfloat16):

@@ -139,3 +139,86 @@ def test_engine_nhwc_planes_equal_nchw_planes():
         eng_a.step(policy, value)
         eng_b.step(policy, value)
     eng_a.close(); eng_b.close()
+
+
+def _pack_bits128(img):
+    """[B,64,128] 0/1 image -> [B,1024] uint8 in the engine's SZ_PLANES_NHWC128_BITS layout (inverse of unpack_bits128)"""
+    B = img.shape[0]
+    bits = img.to(torch.uint8).view(B, 16, 4, 16, 8)                 # [q][psub][cq][k]
+    byte = (bits << torch.arange(8, device=img.device, dtype=torch.uint8)).sum(-1).to(torch.uint8)      # [B,q,psub,cq]
+    return byte.permute(0, 2, 3, 1).reshape(B, 1024).contiguous()     # [psub][cq][q]
+
+
+def test_engine_bit_planes_equal_nhwc_planes():
+    """SZ_PLANES_NHWC128_BITS (1 KiB per board) decodes to exactly the bf16 NHWC image, white and black to move, with history"""
+    from sigma_zero_amd.selfplay import unpack_bits128
+    eng_a = SelfPlayEngine(None, {"C": 2, "num_searches": 12}, 16, chess960=True, planes_dtype="nhwc128")
+    eng_b = SelfPlayEngine(None, {"C": 2, "num_searches": 12}, 16, chess960=True, planes_dtype="bits128")
+    sch = list(range(300, 316))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    urng = np.random.RandomState(0)
+    for e in (eng_a, eng_b):
+        e.new_games(sch)
+    for ply in range(3):
+        for e in (eng_a, eng_b):
+            e.begin()
+        for step in range(12):
+            torch.cuda.synchronize()
+            assert eng_b.planes.dtype == torch.uint8 and eng_b.planes.shape == (16, 1024)
+            assert torch.equal(unpack_bits128(eng_b.planes), eng_a.planes), "ply %d step %d" % (ply, step)
+            assert torch.equal(_pack_bits128(eng_a.planes.float()), eng_b.planes)
+            policy = torch.softmax(torch.randn(16, N.SZ_ACTIONS, generator=g, device="cuda"), 1).contiguous()
+            value = torch.rand(16, generator=g, device="cuda") * 2 - 1
+            eng_a.step(policy, value)
+            eng_b.step(policy, value)
+        u = urng.random_sample(16)
+        for e in (eng_a, eng_b):
+            e.play(u)
+            e.fetch_ply()
+    eng_a.close(); eng_b.close()
+
+
+def test_fastnet_bit_planes_input_is_bit_identical():
+    """the stem expands bit-packed planes to the same LDS tile: outputs equal the bf16-NHWC-input run bit for bit
+    (per-block kernels and the persistent whole-tower kernel; ragged batch)"""
+    torch.manual_seed(5)
+    net = sz.policyNN({}).cuda().eval()
+    fast = FastPolicyNet(net)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = planes_nchw_to_nhwc128((torch.rand(37, 119, 8, 8, generator=g, device="cuda") < 0.15).float())
+    xb = _pack_bits128(x.float())
+    for persistent in (True, False):
+        fast.persistent_tower = persistent
+        p0, v0 = fast(x, inference=True); p0, v0 = p0.clone(), v0.clone()
+        p1, v1 = fast(xb, inference=True)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), persistent
+    with pytest.raises(ValueError):
+        FastPolicyNet(net, mfma16=False)(xb, inference=True)
+
+
+def test_fused_heads_match_separate_head_kernels():
+    """sz_nn_heads_bf16 (one pass over the tower output) against conv_p1 + policy head + value head launches: same bf16 intermediate and
+    the same MFMA products, so logits are identical; softmax / conv_v1 sums differ only in f32 summation order (1e-5)."""
+    torch.manual_seed(11)
+    net = sz.policyNN({}).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g, device="cuda") * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g, device="cuda") + 0.5)
+    net.conv_p2.bias.data.copy_(torch.randn(73, generator=g, device="cuda"))
+    fast = FastPolicyNet(net)
+    assert fast.fused_heads
+    for B in (37, 2, 1):
+        x = planes_nchw_to_nhwc128((torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.15).float())
+        for inference in (True, False):
+            fast.fused_heads = False
+            p0, v0 = fast(x, inference=inference); p0, v0 = p0.clone(), v0.clone()
+            fast.fused_heads = True
+            p1, v1 = fast(x, inference=inference)
+            if inference:
+                assert torch.allclose(p0, p1, rtol=2e-5, atol=1e-10), float((p0 - p1).abs().max())
+                assert torch.allclose(p1.sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+            else:
+                assert torch.equal(p0, p1)
+            assert float((v0 - v1).abs().max()) < 1e-5, float((v0 - v1).abs().max())

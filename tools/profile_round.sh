@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
+#   1. rocprofv3 --kernel-trace --stats of the default bench workload (1 warm-up + 1 timed ply)  -> gpurun_out/<tag>_kernel_stats.csv
+#   2. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ) of the tree kernels and of the fused block kernel -> gpurun_out/<tag>_pmc_*.txt
+# Traces are written under /tmp (they exceed what gpurun copies back); only the summaries are kept.
+set -e -o pipefail
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
+cp $(find /tmp/prof_$TAG/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+echo "stats done"
+for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU"; do
+    name=$(echo $spec | cut -d' ' -f1)
+    rocprofv3 --pmc $spec --output-format csv -d /tmp/prof_$TAG/tree_$name -o run -- python3 $ROOT/tools/tree_pmc.py bits128 > /dev/null 2>> $OUT/${TAG}_pmc.err
+    echo "== $spec" >> $OUT/${TAG}_pmc_tree_kernels_B4096.txt
+    python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/tree_$name k_search_step k_search_begin k_play >> $OUT/${TAG}_pmc_tree_kernels_B4096.txt
+    echo "tree $name done"
+done
+for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    name=$(echo $spec | cut -d' ' -f1)
+    rocprofv3 --pmc $spec --output-format csv -d /tmp/prof_$TAG/block_$name -o run -- python3 $ROOT/tools/block_pmc.py > /dev/null 2>> $OUT/${TAG}_pmc.err
+    echo "== $spec" >> $OUT/${TAG}_pmc_k_block16_B4096.txt
+    python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/block_$name k_block16 >> $OUT/${TAG}_pmc_k_block16_B4096.txt
+    echo "block $name done"
+done

@@ -6,7 +6,7 @@ import numpy as np, torch
 from sigma_zero_amd import _native as N
 from sigma_zero_amd.selfplay import SelfPlayEngine
 B, S = 4096, 128
-eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=False, learning=True, planes_dtype="nhwc128")
+eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=False, learning=True, planes_dtype=(sys.argv[1] if len(sys.argv) > 1 else "bits128"))
 eng.new_games([-1] * B)
 g = torch.Generator(device="cuda").manual_seed(0)
 policy = torch.softmax(torch.randn(B, N.SZ_ACTIONS, generator=g, device="cuda"), 1).contiguous()
