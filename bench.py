@@ -262,9 +262,9 @@ def main():
                 ctf = conv_flop / (conv_ms * 1e-3) / 1e12
                 traffic, traffic_src = None, None          # HBM bytes per launch from committed rocprofv3 --pmc passes
                 try:
-                    with open(os.path.join(ROOT, "profiles", "pmc_conv_latest.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", "pmc_tower_latest.json" if whole else "pmc_conv_latest.json")) as f:
                         traffic_src = json.load(f)
-                    traffic = traffic_src["hbm_bytes_per_launch"] if (fused and not whole and B == 4096) else None
+                    traffic = traffic_src["hbm_bytes_per_launch"] if ((fused or whole) and B == 4096 and (not whole or traffic_src.get("planes") == a.planes)) else None
                 except Exception:
                     pass
                 out["roofline"] = {"kernel": "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole

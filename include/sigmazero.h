@@ -158,6 +158,9 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
  * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128). */
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
+/* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records
+ * s_memtime at the phase boundaries of one block (tools/tower_stamps.py); NULL switches back to the shipped kernel */
+int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
 /* Heads of policyNN (network.py:141-174) as two small kernels:
  *  policy: t = relu(bn(conv_p1(x))) [n_boards,64,256] bf16 -> conv_p2 + bias -> (softmax) -> probs [n_boards,4672] f32 in the
  *          reference's flatten order (plane*64 + row*8 + col); w_packed from sz_nn_pack_head16(conv_p2.weight [73,256]);

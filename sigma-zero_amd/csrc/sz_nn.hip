@@ -52,11 +52,22 @@ __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
 #define NN_COUT 256
 #define NN_NI 2                                            // channel tiles (32) per wave
 #define NN_PAD16 32                                        // LDS row padding of the 16x16x32 path (bytes)
+#define NN_ZERO16 768                                      // zero region behind the rows of a 16x16x32-path image (see conv_kloop16 tap_addr)
+#ifndef NN_ILV
+#define NN_ILV 1                                           // K loop of the 16x16x32 path: memory instructions interleaved into the MFMA gaps (0 = issued in front of each group)
+#endif
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    __bf16 x = (__bf16)a, y = (__bf16)b;                   // v_cvt_pk_bf16_f32: round-to-nearest-even
-    uint16_t xb = __builtin_bit_cast(uint16_t, x), yb = __builtin_bit_cast(uint16_t, y);
-    return (uint32_t)xb | ((uint32_t)yb << 16);
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));       // ONE v_cvt_pk_bf16_f32 (round-to-nearest-even)
+}
+// ReLU on a packed bf16 pair: a negative bf16 is a negative int16, so max(x, 0) per 16-bit half is the ReLU (v_pk_max_i16; -0 -> +0)
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t x) {
+    i16x2 v = __builtin_bit_cast(i16x2, x), z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
 }
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
@@ -84,7 +95,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
         const int c = tid + i * 256;
         *(uint4*)(lds + (c / CHUNKS_PER_POS) * PITCH + (c % CHUNKS_PER_POS) * 16) = stage[i];
     }
-    for (int c = tid; c < PITCH / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    for (int c = tid; c < (PAD == NN_PAD16 ? NN_ZERO16 : PITCH) / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
 }
 
 // ---- stage WGB boards from the engine's bit-packed planes (SZ_PLANES_NHWC128_BITS: 1 KiB per board) ----------
@@ -110,7 +121,7 @@ __device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16
             *(uint4*)(lds + (board * 64 + pos) * PITCH + cq * 16) = o;
         }
     }
-    for (int c = threadIdx.x; c < PITCH / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
 }
 
 // ---- the K loop: acc[i][j] += W[tap,k] x Act[tap,k]^T over all taps and channels ----------------------------
@@ -274,9 +285,10 @@ __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uin
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false>
+template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */>
 __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip, bool wprobe = false,
-                                             uint4 (*ring_in)[4] = nullptr) {
+                                             uint4 (*ring_in)[4] = nullptr, const int img_off = 0 /* byte offset of the image inside `lds` */,
+                                             const float* __restrict__ bias = nullptr /* accumulators start at the bias (C layout: channel = 16*tile + 4*(lane>>4) + reg) */) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;             // 34 slots of 16 B per row: (2p + kg) mod 16 is a permutation per lane group
     constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
     constexpr int ZERO_ROW = WGB * 64;
@@ -287,9 +299,11 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
     const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < NI; i++)
+    for (int i = 0; i < NI; i++) {
+        const f32x4 b4 = bias ? *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; j++) acc[i][j] = b4;
+    }
     constexpr int PF = RING - 1;                           // weight prefetch distance in k-steps (512 matrix-pipe cycles each)
     static_assert(KSTEPS % RING == 0, "ring slots must be compile-time indices");
     uint4 aring[RING][NI];
@@ -300,13 +314,19 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
             if constexpr (PREFETCHED) aring[s][i] = ring_in[s][i];
             else aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
         }
+    // the image's offset is folded into the per-lane row address, so the k offset still fits the 16-bit immediate of ds_read for the
+    // second image of the persistent tower, which sits beyond 64 KB (otherwise every read pays a v_add)
     auto tap_addr = [&](int tap, int j) -> int {
         const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
         int pos = (j & 3) * 16 + p16;                      // position inside its board (board = j >> 2)
         int y = (pos >> 3) + dy, x = (pos & 7) + dx;
         bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
-        int row = ok ? ((j >> 2) * 64 + y * 8 + x) : ZERO_ROW;
-        return row * PITCH + kg * 16;
+        // Off-board taps read zeros.  ds_read_b128 is conflict-free when the 16 lanes of a group hit 16 different 16-byte slots mod 256 B;
+        // a valid lane's slot is (2*row + kg + 4*kc) mod 16 and the rows of a group are consecutive, which makes that a permutation.  An
+        // off-board lane therefore reads the zero region (768 B, 256-B aligned) at the slot its VIRTUAL row would have had, instead of
+        // one shared zero row that collides with some valid lane's slot.
+        const int vrow = pos + 8 * ((NTAPS == 9) ? tap / 3 - 1 : 0) + dx;
+        return img_off + (ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : ZERO_ROW * PITCH + ((2 * vrow + kg) & 15) * 16);
     };
     int bcur[NJ], bnxt[NJ];
     bf16x8 bfrag[2][NH];
@@ -324,29 +344,49 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
             const int ks = tap * KSTEPS + kc;
 #pragma unroll
             for (int hs = 0; hs < 2; hs++) {
-                if (hs == 0 && ks + PF < TOTAL_KS) {        // weights PF k-steps ahead (slot freed by the previous half-step)
+                if (!NN_ILV) {
+                    if (hs == 0 && ks + PF < TOTAL_KS) {        // weights PF k-steps ahead (slot freed by the previous half-step)
 #pragma unroll
-                    for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
+                        for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
+                    }
+                    // activations of the next half-step
+                    if (hs == 0) {
+#pragma unroll
+                        for (int j = 0; j < NH; j++) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
+                    } else if (kc + 1 < KSTEPS) {
+#pragma unroll
+                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
+                    } else if (tap + 1 < NTAPS) {
+#pragma unroll
+                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bnxt[j]);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // activations of the next half-step
-                if (hs == 0) {
-#pragma unroll
-                    for (int j = 0; j < NH; j++) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
-                } else if (kc + 1 < KSTEPS) {
-#pragma unroll
-                    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
-                } else if (tap + 1 < NTAPS) {
-#pragma unroll
-                    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bnxt[j]);
-                }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
-                    for (int j = 0; j < NH; j++)
+                    for (int j = 0; j < NH; j++) {
                         acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], acc[i][hs * NH + j], 0, 0, 0);
+                        if (NN_ILV) {
+                            // one memory instruction per MFMA gap (an MFMA leaves 8 of its 16 cycles for other issue): first the next
+                            // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2)
+                            const int m = i * NH + j;
+                            if (m < NH) {
+                                if (ABL & 2) {}
+                                else if (hs == 0) bfrag[1][m] = *(const bf16x8*)(lds + bcur[NH + m] + kc * 64);
+                                else if (kc + 1 < KSTEPS) bfrag[0][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
+                                else if (tap + 1 < NTAPS) bfrag[0][m] = *(const bf16x8*)(lds + bnxt[m]);
+                            } else if (m < NH + NI) {
+                                if (ABL & 1) {}
+                                else if (hs == 0 && ks + PF < TOTAL_KS)
+                                    aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + (m - NH) * 64];
+                            }
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -356,6 +396,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     }
 }
 
+// bias == nullptr: the accumulators already started at the bias (conv_kloop16's `bias` argument)
 template <int WGB>
 __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias, bool relu) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
@@ -367,10 +408,12 @@ __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&a
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = (wave * 4 + i) * 16 + 4 * kg;    // C layout: col = lane&15 (position), row = 4*(lane>>4) + reg (channel)
-            f32x4 b4 = *(const f32x4*)(bias + co);
-            float v0 = acc[i][j][0] + b4[0], v1 = acc[i][j][1] + b4[1], v2 = acc[i][j][2] + b4[2], v3 = acc[i][j][3] + b4[3];
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+            f32x4 v = acc[i][j];
+            if (bias) v += *(const f32x4*)(bias + co);      // (no "+ 0.f" otherwise: it is not a no-op for -0 and would stay in the code)
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            if (relu) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
             *(uint2*)(lds + row * OPITCH + co * 2) = o;
         }
     }
@@ -442,9 +485,9 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : 1)) void k_conv16_bf16(const u
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
-    conv_kloop16<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0, (flags & 0x100000) != 0);
+    conv_kloop16<CIN, NTAPS, WGB>(lds, w, acc, (flags & 8) != 0, (flags & 0x100000) != 0, nullptr, 0, bias);
     __syncthreads();
-    if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds16<WGB>(lds, acc, bias, false);
+    if (!((flags & 4) && acc[0][0][0] != 12345.f)) acc_to_lds16<WGB>(lds, acc, nullptr, false);
     __syncthreads();
     if (!(flags & 4)) lds_to_out<WGB, NN_PAD16>(lds, res, out, board0, n_boards, (flags & 1) != 0);
 }
@@ -461,13 +504,13 @@ __global__ __launch_bounds__(256, (WGB == 2 ? 2 : (WGB == 1 ? 3 : 1))) void k_bl
     __syncthreads();
     if (WGB == 2) phase_stagger(flags, n_cu);
     f32x4 acc[4][4 * WGB];
-    conv_kloop16<256, 9, WGB>(lds, w1, acc, false);
+    conv_kloop16<256, 9, WGB>(lds, w1, acc, false, false, nullptr, 0, b1);
     __syncthreads();
-    acc_to_lds16<WGB>(lds, acc, b1, true);
+    acc_to_lds16<WGB>(lds, acc, nullptr, true);
     __syncthreads();
-    conv_kloop16<256, 9, WGB>(lds, w2, acc, false);
+    conv_kloop16<256, 9, WGB>(lds, w2, acc, false, false, nullptr, 0, b2);
     __syncthreads();
-    acc_to_lds16<WGB>(lds, acc, b2, false);
+    acc_to_lds16<WGB>(lds, acc, nullptr, false);
     __syncthreads();
     if (nt) lds_to_out<WGB, NN_PAD16, true>(lds, in, out, board0, n_boards, true);
     else if ((flags & 0xC00000) == 0xC00000) lds_to_out<WGB, NN_PAD16, true, true>(lds, in, out, board0, n_boards, true);
@@ -613,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
                                                           float* __restrict__ probs, float* __restrict__ v1_out, int n_boards, int do_softmax) {
     constexpr int WGB = 2, PITCH = NN_COUT * 2 + NN_PAD16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* red = (float*)(lds + (WGB * 64 + 1) * PITCH);    // [4 waves][2]: softmax max / sum exchange between the two waves of a board
+    float* red = (float*)(lds + WGB * 64 * PITCH + NN_ZERO16);    // [4 waves][2]: softmax max / sum exchange between the two waves of a board
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;
     const int board0 = blockIdx.x * WGB;
@@ -642,9 +685,9 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
         if (!(lane & 1) && board < n_boards) v1_out[(size_t)board * 64 + (row & 63)] = fmaxf(tot + bv, 0.f);
     }
     f32x4 acc[4][4 * WGB];
-    conv_kloop16<256, 1, WGB>(lds, w_p1, acc, false);
+    conv_kloop16<256, 1, WGB>(lds, w_p1, acc, false, false, nullptr, 0, b_p1);
     __syncthreads();
-    acc_to_lds16<WGB>(lds, acc, b_p1, true);               // t over x, in the layout the MFMA B operand is read from
+    acc_to_lds16<WGB>(lds, acc, nullptr, true);               // t over x, in the layout the MFMA B operand is read from
     __syncthreads();
     // policy logits: wave -> board wave>>1, position tiles 2*(wave&1) + {0,1}; 5 channel tiles (73 padded to 80), K = 256
     const int pboard = wave >> 1, j0 = (wave & 1) * 2;
@@ -716,7 +759,8 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
     }
 }
 
-// x <- relu(acc + bias + x) in place on the LDS image (f32 add, one bf16 rounding): every lane owns its 4 channels x 1 position
+// x <- relu(acc + bias + x) in place on the LDS image (f32 add, one bf16 rounding): every lane owns its 4 channels x 1 position.
+// bias == nullptr: the accumulators already started at the bias.
 template <int WGB>
 __device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
@@ -728,12 +772,13 @@ __device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, cons
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = (wave * 4 + i) * 16 + 4 * kg;
-            f32x4 b4 = *(const f32x4*)(bias + co);
+            f32x4 v = acc[i][j];
+            if (bias) v += *(const f32x4*)(bias + co);
             uint2* px = (uint2*)(xlds + row * OPITCH + co * 2);
             const uint2 r = *px;
-            float v0 = fmaxf(acc[i][j][0] + b4[0] + bf16_lo(r.x), 0.f), v1 = fmaxf(acc[i][j][1] + b4[1] + bf16_hi(r.x), 0.f);
-            float v2 = fmaxf(acc[i][j][2] + b4[2] + bf16_lo(r.y), 0.f), v3 = fmaxf(acc[i][j][3] + b4[3] + bf16_hi(r.y), 0.f);
-            uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+            uint2 o;
+            o.x = relu_bf16x2(pack_bf16x2(v[0] + bf16_lo(r.x), v[1] + bf16_hi(r.x)));
+            o.y = relu_bf16x2(pack_bf16x2(v[2] + bf16_lo(r.y), v[3] + bf16_hi(r.y)));
             *px = o;
         }
     }
@@ -754,15 +799,22 @@ struct TowerParams {
     const float* b[NN_MAX_CONVS];
 };
 
-__global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags) {
+// STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
+// a buffer of their own; the shipped instantiation (STAMP = false) executes no stamp.
+#define TSTAMP(k) do { if (STAMP_ && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
+template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 1/2/3 (results garbage) */>
+__global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags,
+                                                          unsigned long long* __restrict__ stamps) {
+    constexpr bool STAMP_ = MODE != 0;
+    constexpr int ABL = MODE >= 2 ? MODE - 1 : 0;
     constexpr int WGB = 2;
-    constexpr int IMG = (WGB * 64 + 1) * (NN_COUT * 2 + NN_PAD16);       // one activation image incl. its zero row
+    constexpr int IMG = WGB * 64 * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16;  // one activation image incl. its zero region
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* bufX = lds;
     unsigned char* bufT = lds + IMG;
     const int n_tiles = (n_boards + WGB - 1) / WGB;
     // zero rows of both 256-channel images (row index 128); the stem's own zero row is rewritten by stage_tile
-    for (int c = threadIdx.x; c < (NN_COUT * 2 + NN_PAD16) / 16; c += 256) {
+    for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) {
         *(uint4*)(bufX + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
         *(uint4*)(bufT + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -775,19 +827,28 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(bufT, planes, board0, n_boards);
         else stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
         __syncthreads();
-        conv_kloop16<128, 9, WGB, 4, true>(bufT, prm.w[0], acc, false, false, ring);     // stem: x = relu(bn(conv1(planes)))
+        conv_kloop16<128, 9, WGB, 4, true>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0]);  // stem (reads bufT): x = relu(bn(conv1(planes)))
         if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
-        acc_to_lds16<WGB>(bufX, acc, prm.b[0], true);
+        acc_to_lds16<WGB>(bufX, acc, nullptr, true);
         __syncthreads();
         for (int blk = 0; blk < n_blocks; blk++) {
-            conv_kloop16<256, 9, WGB, 4, true>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring);
+            const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
+            TSTAMP(0);
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk]);
+            TSTAMP(1);
             conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
-            acc_to_lds16<WGB>(bufT, acc, prm.b[1 + 2 * blk], true);   // t = relu(bn1(conv1(x)))   (bufT is idle: last read before the barrier above)
+            acc_to_lds16<WGB>(bufT, acc, nullptr, true);   // t = relu(bn1(conv1(x)))   (bufT is idle: last read before the barrier above)
+            TSTAMP(2);
             __syncthreads();
-            conv_kloop16<256, 9, WGB, 4, true>(bufT, prm.w[2 + 2 * blk], acc, false, false, ring);
+            TSTAMP(3);
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk]);   // reads bufT
+            TSTAMP(4);
             if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
-            acc_residual_inplace16<WGB>(bufX, acc, prm.b[2 + 2 * blk]);   // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+            acc_residual_inplace16<WGB>(bufX, acc, nullptr);   // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+            TSTAMP(5);
             __syncthreads();
+            TSTAMP(6);
+            if (STAMP_ && stamp_now && (threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
         lds_to_out<WGB, NN_PAD16>(bufX, nullptr, out, board0, n_boards, false);
     }
@@ -841,7 +902,7 @@ template <int WGB> static int launch_block(const void* in, const void* w1, const
 
 template <int CIN, int NTAPS> static int launch_conv16(const void* in, const void* w, const float* bias, const void* res, void* out, int n_boards, int flags, hipStream_t s) {
     constexpr int WGB = 2, PITCH = CIN * 2 + NN_PAD16;
-    const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + NN_PAD16);
+    const size_t lds_in = (size_t)(WGB * 64) * PITCH + NN_ZERO16, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + NN_PAD16);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     static bool attr_set = false;
     if (!attr_set) {
@@ -854,7 +915,7 @@ template <int CIN, int NTAPS> static int launch_conv16(const void* in, const voi
     return SZ_OK;
 }
 template <int WGB> static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
-    const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + NN_PAD16);
+    const size_t lds = (size_t)(WGB * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_block16_bf16<WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -919,6 +980,11 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
     return SZ_OK;
 }
 
+// diagnostic: device buffer of 8 u64 per wave (256 workgroups x 4 waves) that receives the phase stamps of the STAMP build; NULL = off
+static unsigned long long* g_tower_stamps = nullptr;
+static int g_tower_mode = 1;
+int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode) { g_tower_stamps = (unsigned long long*)dev_buffer; g_tower_mode = mode; return SZ_OK; }
+
 // Whole tower (stem + n_blocks BasicBlocks) in one persistent launch.  planes [n_boards,64,128] bf16 (NHWC, 119 real channels),
 // out [n_boards,64,256] bf16.  w/b: n_convs = 1 + 2*n_blocks device pointers each (weights from sz_nn_pack_weights16, stem with
 // cin_padded 128; biases [256] f32 with BatchNorm folded), given as HOST arrays of device pointers.
@@ -930,14 +996,25 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         if (!w_packed[i] || !bias[i]) return SZ_ERR_INVALID;
         prm.w[i] = (const uint4*)w_packed[i]; prm.b[i] = bias[i];
     }
-    const size_t lds = 2 * (size_t)(2 * 64 + 1) * (NN_COUT * 2 + NN_PAD16);
+    const size_t lds = 2 * ((size_t)(2 * 64) * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
-    hipLaunchKernelGGL(k_tower16_bf16, dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags);
+    const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
+#define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
+    if (!g_tower_stamps) TOWER_LAUNCH(0);
+    else if (g_tower_mode == 2) TOWER_LAUNCH(2);
+    else if (g_tower_mode == 3) TOWER_LAUNCH(3);
+    else if (g_tower_mode == 4) TOWER_LAUNCH(4);
+    else TOWER_LAUNCH(1);
+#undef TOWER_LAUNCH
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
@@ -972,7 +1049,7 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
                      const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch,
                      int32_t n_boards, int32_t do_softmax, void* stream) {
     if (!x || !w_p1_packed || !b_p1 || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0) return SZ_ERR_INVALID;
-    const size_t lds_h = (size_t)(2 * 64 + 1) * (256 * 2 + NN_PAD16) + 64, lds_v = (64 * 256 + 4 * 64) * sizeof(float);
+    const size_t lds_h = (size_t)(2 * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16 + 64, lds_v = (64 * 256 + 4 * 64) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));

@@ -78,7 +78,9 @@ class FastPolicyNet:
         self.fused_heads = self.w16          # one pass over the tower output for both heads (sz_nn_heads_bf16)
         # whole-tower persistent kernel (sz_nn_tower_bf16): host arrays of device pointers, 16x16x32 weight order only
         self.persistent_tower = self.w16
-        self.persistent_max_boards = 1024     # measured: one launch for the whole tower wins at small batches, per-block launches at 4096
+        # measured (tools/tower_vs_blocks.py): one launch for the whole tower beats 20 per-layer launches at every batch size since the
+        # K loop interleaves its loads into the MFMA gaps (B=512: 0.96 vs 1.23 ms, B=4096: 7.48 vs 7.67 ms); lower this to force per-block launches
+        self.persistent_max_boards = 1 << 30
         if self.w16:
             ws = [self.stem[0]] + [w for blk in self.blocks for w in (blk[0], blk[2])]
             bs = [self.stem[1]] + [b for blk in self.blocks for b in (blk[1], blk[3])]

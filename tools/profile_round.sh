@@ -20,6 +20,13 @@ for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST
     python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/tree_$name k_search_step k_search_begin k_play >> $OUT/${TAG}_pmc_tree_kernels_B4096.txt
     echo "tree $name done"
 done
+for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+    name=$(echo $spec | cut -d' ' -f1)
+    rocprofv3 --pmc $spec --output-format csv -d /tmp/prof_$TAG/tower_$name -o run -- python3 $ROOT/tools/tower_pmc.py 4096 bits > /dev/null 2>> $OUT/${TAG}_pmc.err
+    echo "== $spec" >> $OUT/${TAG}_pmc_k_tower16_B4096.txt
+    python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/tower_$name k_tower16 >> $OUT/${TAG}_pmc_k_tower16_B4096.txt
+    echo "tower $name done"
+done
 for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     name=$(echo $spec | cut -d' ' -f1)
     rocprofv3 --pmc $spec --output-format csv -d /tmp/prof_$TAG/block_$name -o run -- python3 $ROOT/tools/block_pmc.py > /dev/null 2>> $OUT/${TAG}_pmc.err

@@ -1,0 +1,35 @@
+"""In-kernel phase timing of the persistent tower (diagnostic build, MI355X_MICROARCH.md 'DVFS give-back' item 6):
+cycles of K loop / epilogue / barrier for block 3 of each workgroup's second tile, and the shader clock held under load."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C, numpy as np, torch
+import sigma_zero_amd as sz
+from sigma_zero_amd import _native as N
+from sigma_zero_amd.fastnet import FastPolicyNet, planes_nchw_to_nhwc128
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+torch.manual_seed(0)
+fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+fast.persistent_max_boards = 1 << 30
+planes = planes_nchw_to_nhwc128((torch.rand(B, 119, 8, 8, device="cuda") < 0.12).float())
+t_end = time.time() + 2.0
+while time.time() < t_end:                       # >= 2 s of back-to-back launches so the clock has settled
+    fast.tower(planes)
+torch.cuda.synchronize()
+modes = [int(m) for m in sys.argv[2:]] or [1]
+names = ["conv1 K loop", "epilogue1 (acc->LDS)", "barrier1", "conv2 K loop", "epilogue2 (residual)", "barrier2"]
+print("ideal K loop = 72 k-steps x 512 = 36864 MFMA cycles")
+for mode in modes:
+    buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+    N.check(N.lib().sz_nn_debug_tower_stamps(C.c_void_p(buf.data_ptr()), mode), "stamps")
+    for _ in range(3):
+        fast.tower(planes)
+    torch.cuda.synchronize()
+    N.lib().sz_nn_debug_tower_stamps(None, 1)
+    s = buf.cpu().numpy().reshape(256, 4, 8).astype(np.float64)
+    s = s[s[:, :, 0] > 0].reshape(-1, 8)
+    d = np.diff(s[:, :7], axis=1)
+    print("mode %d (%s): waves with stamps: %d" % (mode, {1: "full", 2: "no weight loads", 3: "no LDS reads", 4: "MFMA only"}[mode], len(s)))
+    for i, n in enumerate(names):
+        print("  %-22s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (n, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+    tot = s[:, 6] - s[:, 0]
+    print("  block total median %.0f cycles; MFMA-busy fraction %.3f" % (np.median(tot), 2 * 36864 / np.median(tot)))
