@@ -56,6 +56,28 @@ def test_collate_unpacks_like_reference():
     assert batch["rewards"].tolist() == [1, -1, 0, 1, -1]
 
 
+def test_device_batches_equal_dataloader_with_collate():
+    """DeviceBatches (gather + bit unpack + scatter on the training device) yields the DataLoader + collatefn batches bit for bit"""
+    rng = np.random.RandomState(1)
+    n = 37
+    planes = rng.rand(n, 119, 8, 8) < 0.2
+    packed = list((planes.astype(np.uint8) * (1 << np.arange(8)).astype(np.uint8)).sum(-1).astype(np.uint8))
+    aidx = [np.sort(rng.choice(4672, size=rng.randint(1, 40), replace=False)) for _ in range(n)]
+    aprob = [(lambda v: v / v.sum())(rng.rand(len(a))) for a in aidx]
+    rew = [float(rng.choice([-1, 0, 1])) for _ in range(n)]
+    ds = train_rl.SelfPlayDataset(packed, aidx, aprob, rew)
+    dl = torch.utils.data.DataLoader(ds, batch_size=8, shuffle=False, drop_last=True, collate_fn=train_rl.SelfPlayDataset.collate)
+    db = train_rl.DeviceBatches(packed, aidx, aprob, rew, batch_size=8, device="cpu", shuffle=False)
+    assert len(db) == len(dl) == 4
+    for a, b in zip(dl, db):
+        for k in ("states", "actions", "rewards"):
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+    # shuffled: a permutation of the same samples, every sample at most once per pass, last partial batch dropped
+    g = torch.Generator().manual_seed(3)
+    seen = torch.cat([b["rewards"] for b in train_rl.DeviceBatches(packed, aidx, aprob, rew, batch_size=8, device="cpu", shuffle=True, generator=g)])
+    assert seen.numel() == 32
+
+
 def _make_batch(seed, n):
     g = torch.Generator().manual_seed(seed)
     return {"states": (torch.rand(n, 119, 8, 8, generator=g) < 0.15).float(),
