@@ -50,21 +50,10 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     games = [dict(states=[], actions=[], rewards=[], colours=[], result=None) for _ in range(n_games)]
     alive = np.ones(n_games, dtype=bool)
     ply = 0
-    while alive.any() and ply < max_plies:
-        eng.search()
-        eng.check_errors()
-        u = np.zeros(n_games, dtype=np.float64)
-        for g in range(n_games):
-            if alive[g]:
-                u[g] = uniforms(g, ply) if uniforms is not None else np.random.random_sample()
-        eng.play(u)
-        rec = eng.fetch_ply()
-        st = eng.stats()
-        if st["boards_error"]:
-            eng.check_errors()
-        for g in range(n_games):
-            if not alive[g] or not rec["active"][g]:
-                continue
+
+    def absorb(rec, was_alive):
+        """host-side bookkeeping of one ply's records (sim.py:71-73); runs while the GPU searches the next ply"""
+        for g in np.nonzero(was_alive & rec["active"].astype(bool))[0]:
             k = int(rec["n_child"][g])
             white = bool(rec["colour"][g])
             acts = rec["action"][g, :k]
@@ -75,11 +64,31 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
             games[g]["actions"].append({m: int(v) / total for m, v in zip(moves, vis)})
             games[g]["colours"].append(white)
             if rec["game_over"][g]:
-                alive[g] = False
                 games[g]["result"] = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}[int(rec["result"][g])]
+
+    pending = None
+    while alive.any() and ply < max_plies:
+        eng.search()                                       # enqueues num_searches x (network + tree step); returns before the GPU is done
+        if pending is not None:
+            absorb(*pending)                               # previous ply's records, overlapped with this ply's search
+            pending = None
+        eng.check_errors()
+        u = np.zeros(n_games, dtype=np.float64)
+        for g in range(n_games):
+            if alive[g]:
+                u[g] = uniforms(g, ply) if uniforms is not None else np.random.random_sample()
+        eng.play(u)
+        rec = eng.fetch_ply()
+        st = eng.stats()
+        if st["boards_error"]:
+            eng.check_errors()
+        pending = (rec, alive.copy())
+        alive &= ~(rec["game_over"].astype(bool) & rec["active"].astype(bool))
         ply += 1
         if verbose:
             print("ply %d: %d games alive" % (ply, int(alive.sum())))
+    if pending is not None:
+        absorb(*pending)
     for g in range(n_games):
         reward = {"1-0": 1, "0-1": -1}.get(games[g]["result"], 0)
         games[g]["rewards"] = [reward if i % 2 == 0 else -reward for i in range(len(games[g]["actions"]))]   # sim.py:94-97
