@@ -472,3 +472,62 @@ def test_slot_refill_keeps_other_boards_intact():
     _, visits, n_child, _, _ = eng.root_children()
     assert all(visits[b, :n_child[b]].sum() == S - 1 for b in range(B))
     eng.close()
+
+
+def test_full_size_invariants_4096_boards_800_searches():
+    """BASELINE config 3 at full size through size-independent properties (the oracle cannot follow 3.3 M simulations): every
+    simulation is accounted for, every root's child visits sum to S-1 (mcts.py:46,118), the sampled move is a visited root child,
+    records are complete, no board reports an error, edge capacity is not approached."""
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    B, S = 4096, 800
+    torch.manual_seed(0)
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    eng = SelfPlayEngine(fast, {"C": 2, "num_searches": S}, B, chess960=True, learning=True, planes_dtype="bits128")
+    prng = np.random.RandomState(5)
+    eng.new_games(prng.randint(0, 960, size=B).tolist())
+    st0 = eng.stats()
+    eng.search()
+    st = eng.check_errors()
+    assert st["simulations"] - st0["simulations"] == B * S
+    assert st["expansions"] + st["terminal_hits"] - st0["expansions"] - st0["terminal_hits"] == B * S
+    assert st["max_edges_used"] < S * 64 + 256
+    action, visits, n_child, prior, wsum = eng.root_children()
+    k = np.arange(visits.shape[1])[None, :] < n_child[:, None]
+    assert (n_child >= 1).all() and (n_child <= 218).all()
+    assert ((visits * k).sum(1) == S - 1).all()
+    assert (np.diff(np.where(k, action, 1 << 30), axis=1)[:, :-1][k[:, 1:-1]] > 0).all()          # ascending action order
+    assert (np.abs(np.where(k, wsum, 0)) <= np.where(k, visits, 0) + 1e-9).all()                   # |W| <= N
+    psum = np.where(k, prior, 0).sum(1)                                                             # 0.75*1 + 0.25*K*noise
+    assert np.allclose(psum, 0.75 + 0.25 * n_child * float(np.float32(1) - np.float32(2.0 ** -24)), atol=1e-3)
+    u = prng.random_sample(B)
+    eng.play(u)
+    rec = eng.fetch_ply()
+    assert rec["active"].all() and (rec["n_child"] == n_child).all()
+    for b in range(0, B, 97):
+        kk = int(n_child[b])
+        assert rec["chosen"][b] in action[b, :kk] and visits[b, :kk][list(action[b, :kk]).index(rec["chosen"][b])] > 0
+    eng.close()
+
+
+def test_search_is_bitwise_reproducible_with_the_mfma_network():
+    """same seeds, same weights -> identical visit counts and priors on two fresh engines (no atomics, fixed summation orders)"""
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    torch.manual_seed(3)
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    outs = []
+    for rep in range(2):
+        eng = SelfPlayEngine(fast, {"C": 2, "num_searches": 60}, 130, chess960=True, learning=True, planes_dtype="bits128")
+        eng.new_games(list(range(200, 330)))
+        urng = np.random.RandomState(9)
+        res = []
+        for ply in range(3):
+            eng.search()
+            res.append([a.copy() for a in eng.root_children()])
+            eng.play(urng.random_sample(130))
+            eng.fetch_ply()
+        eng.check_errors()
+        eng.close()
+        outs.append(res)
+    for r0, r1 in zip(*outs):
+        for a, b in zip(r0, r1):
+            assert np.array_equal(a, b)
