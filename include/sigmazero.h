@@ -124,6 +124,12 @@ int sz_play(sz_engine* e, const double* uniforms_dev, void* stream);
 int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t* visits, int32_t* n_child,
                  uint8_t* colour, int32_t* chosen, uint8_t* game_over, int8_t* result, uint8_t* active, void* stream);
 
+/* NON-REFERENCE option, off by default: true AlphaZero root noise.  gamma_dev: device array [n_boards][SZ_MAX_MOVES]
+ * f32 of Gamma(alpha,1) draws, read when a search's ROOT is expanded (the step after sz_search_begin): root prior k becomes
+ * 0.75*p_k + 0.25*g_k/sum_{j<K} g_j (one Dirichlet(alpha) sample over the K legal moves); inner nodes get no noise.  NULL restores
+ * the reference behaviour (mcts.py:91-98: the constant noise_value at every expansion).  Needs learning = 1. */
+int sz_set_root_noise(sz_engine* e, const float* gamma_dev);
+
 /* test / debug readback of the pending leaves: legal-move mask [n_boards,73] uint64 (bit v of word p =
  * action p*64+v), leaf depth, node count, edge count, status per board (host pointers, may be NULL). */
 int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges,

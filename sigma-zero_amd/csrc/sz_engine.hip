@@ -49,6 +49,7 @@ struct alignas(16) Ctl {
 struct View {
     int B, S, n_cap, e_cap, p_cap, learning, chess960, planes_dtype;
     float c_puct, noise;
+    const float* root_gamma;    // optional (non-reference) true Dirichlet root noise: [B][SZ_MAX_MOVES] Gamma(alpha,1) draws; NULL = reference behaviour
     SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
     // per-ply training record
     uint8_t* rec_planes; int* rec_action; int* rec_visits; int* rec_nchild; uint8_t* rec_colour; int* rec_chosen;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
             bool keep = mine && !(p == 0.0f);                          // policy.nonzero() (NaN stays)
             u64 km = __ballot(keep);
             if (keep) {
-                if (v.learning) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
+                if (v.learning && !v.root_gamma) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
                 int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
                 if (slot < v.e_cap) {
                     EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
@@ -445,6 +446,16 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
             kept += __popcll(km);
         }
         if (first + kept > v.e_cap) { err = SZ_ERR_CAPACITY; kept = 0; }
+        if (v.learning && v.root_gamma && d == 0 && kept > 0) {
+            // non-reference option (sz_set_root_noise): AlphaZero's root-only noise.  The K Gamma(alpha,1) draws of this board,
+            // normalised over its K children, are one Dirichlet(alpha) sample of dimension K; inner nodes keep their priors.
+            const float* g = v.root_gamma + (size_t)b * SZ_MAX_MOVES;
+            __threadfence_block();                                      // the children were written by other lanes of this wave
+            float gs = 0.f;
+            for (int c = lane; c < kept; c += 64) gs = gs + g[c];
+            gs = wave_sum_butterfly(gs);
+            for (int c = lane; c < kept; c += 64) bp.es[first + c].P = (0.75f * bp.es[first + c].P) + (0.25f * (g[c] / gs));
+        }
         if (lane == 0) { bp.em[leaf_edge].first = first; bp.em[leaf_edge].n = (unsigned short)kept; }
         n_edges += kept;
         (void)node;
@@ -677,7 +688,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
     if (v.e_cap < SZ_MAX_CHILDREN + 2) v.e_cap = SZ_MAX_CHILDREN + 2;
     v.p_cap = cfg->num_searches + 2;
     v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
-    v.c_puct = cfg->c_puct; v.noise = cfg->noise_value;
+    v.c_puct = cfg->c_puct; v.noise = cfg->noise_value; v.root_gamma = nullptr;
     e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4;
     if (e->lds_bytes > 64 * 1024) { delete e; return SZ_ERR_INVALID; }
     const size_t B = v.B;
@@ -718,6 +729,12 @@ int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, 
     HIPCHK(hipStreamSynchronize(s));                    // host staging buffers go out of scope
     hipLaunchKernelGGL(k_new_games, dim3(e->v.B), dim3(64), e->lds_bytes, s, e->v, e->d_scharnagl, active ? e->d_active : nullptr);
     HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_set_root_noise(sz_engine* e, const float* gamma_dev) {
+    if (!e) return SZ_ERR_INVALID;
+    e->v.root_gamma = gamma_dev;
     return SZ_OK;
 }
 

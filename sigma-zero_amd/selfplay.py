@@ -52,6 +52,10 @@ class SelfPlayEngine:
         self.root_prior = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.float32, device=dev)
         self.root_wsum = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.float64, device=dev)
         self.nn_seconds = 0.0
+        # NON-REFERENCE option (default off): args["root_dirichlet_alpha"] = alpha switches from the reference's noise (the constant
+        # 1-2^-24 at every expansion, mcts.py:91-98) to AlphaZero's Dirichlet(alpha) noise on the root's children only
+        self.root_alpha = self.args.get("root_dirichlet_alpha")
+        self._gamma = None
 
     def close(self):
         if self._e:
@@ -87,7 +91,15 @@ class SelfPlayEngine:
         policy, value = self.model(planes, inference=True)
         return policy.float().contiguous(), value.float().reshape(-1).contiguous()
 
+    def set_root_noise(self, gamma):
+        """gamma: [B, SZ_MAX_MOVES] f32 device tensor of Gamma(alpha,1) draws, or None for the reference behaviour"""
+        self._gamma = None if gamma is None else gamma.to(self.device, torch.float32).contiguous()
+        N.check(N.lib().sz_set_root_noise(self._e, _ptr(self._gamma)), "sz_set_root_noise")
+
     def begin(self):
+        if self.root_alpha is not None:
+            alpha = torch.full((self.B, N.SZ_MAX_MOVES), float(self.root_alpha), device=self.device)
+            self.set_root_noise(torch._standard_gamma(alpha))
         N.check(N.lib().sz_search_begin(self._e, _ptr(self.planes), self._stream()), "sz_search_begin")
 
     def step(self, policy, value):

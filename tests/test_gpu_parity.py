@@ -531,3 +531,43 @@ def test_search_is_bitwise_reproducible_with_the_mfma_network():
     for r0, r1 in zip(*outs):
         for a, b in zip(r0, r1):
             assert np.array_equal(a, b)
+
+
+def test_root_dirichlet_option_is_root_only_and_exact():
+    """NON-REFERENCE option (off by default): with Gamma draws g supplied, root prior k == 0.75*p_k + 0.25*g_k/sum(g[:K]) and the
+    search below the root runs on un-noised priors; without it the reference constant is back."""
+    B, S = 6, 40
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": S}, B, chess960=True, learning=True)
+    eng.new_games([100 + b for b in range(B)])
+    g = torch.Generator(device="cuda").manual_seed(1)
+    gamma = torch._standard_gamma(torch.full((B, N.SZ_MAX_MOVES), 0.3, device="cuda"), generator=g)
+    ev = random_evaluator(3)
+    eng.set_root_noise(gamma)
+    eng.begin()
+    pol0 = None
+    for it in range(S):
+        policy, value = ev(eng.planes, it)
+        if it == 0:
+            pol0 = policy.cpu().numpy()
+        eng.step(policy, value)
+    eng.check_errors()
+    action, visits, n_child, prior, wsum = eng.root_children()
+    gam = gamma.cpu().numpy()
+    for b in range(B):
+        k = int(n_child[b])
+        p = pol0[b, action[b, :k]].astype(np.float32)
+        p = p / p.sum(dtype=np.float32)
+        n = gam[b, :k] / gam[b, :k].sum(dtype=np.float32)
+        want = 0.75 * p + 0.25 * n
+        assert np.allclose(prior[b, :k], want, rtol=2e-6, atol=1e-8), b
+        assert abs(float(prior[b, :k].sum()) - 1.0) < 1e-5 and visits[b, :k].sum() == S - 1
+    # back to the reference noise
+    eng.set_root_noise(None)
+    eng.begin()
+    for it in range(2):
+        policy, value = ev(eng.planes, it)
+        eng.step(policy, value)
+    _, _, n_child, prior, _ = eng.root_children()
+    k = int(n_child[0])
+    assert abs(float(prior[0, :k].sum()) - (0.75 + 0.25 * k * NOISE_REFERENCE)) < 1e-4
+    eng.close()
