@@ -326,7 +326,9 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         // off-board lane therefore reads the zero region (768 B, 256-B aligned) at the slot its VIRTUAL row would have had, instead of
         // one shared zero row that collides with some valid lane's slot.
         const int vrow = pos + 8 * ((NTAPS == 9) ? tap / 3 - 1 : 0) + dx;
-        return img_off + (ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : ZERO_ROW * PITCH + ((2 * vrow + kg) & 15) * 16);
+        int a = img_off + (ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : ZERO_ROW * PITCH + ((2 * vrow + kg) & 15) * 16);
+        asm volatile("" : "+v"(a));                        // opaque: keeps img_off inside the VGPR (hipcc otherwise re-associates it into a per-read v_add)
+        return a;
     };
     int bcur[NJ], bnxt[NJ];
     bf16x8 bfrag[2][NH];
