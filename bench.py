@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--planes", default="bits128", choices=["bits128", "nhwc128"],
                     help="network-input image written by the tree kernel on the fast path: bit-packed (1 KiB/board) or bf16 NHWC (16 KiB/board)")
+    ap.add_argument("--edges-per-board", type=int, default=0, help="child slots per board (0 = engine default: worst case when it fits in half of the free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
@@ -145,10 +146,10 @@ def main():
     if fast:
         from sigma_zero_amd.fastnet import FastPolicyNet
         model = FastPolicyNet(sz.policyNN({}).eval(), device=dev)
-        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=a.planes)
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=a.planes, edges_per_board=a.edges_per_board)
     else:
         model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
-        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype)
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=dtype, edges_per_board=a.edges_per_board)
     rng = np.random.RandomState(1234 + rank)
     import random
     prng = random.Random(rank)

@@ -53,7 +53,8 @@ typedef struct sz_config {
     int32_t learning;            /* search(..., learning=...), mcts.py:91 */
     float   noise_value;         /* value of the degenerate Dirichlet draw of mcts.py:93 (1-2^-24 under torch 2.10) */
     int32_t chess960;            /* boards spell castling king-takes-rook (chess.Board(chess960=True)) */
-    int32_t edges_per_board;     /* child slots per board per search; 0 = num_searches*64+256 */
+    int32_t edges_per_board;     /* child slots per board per search; 0 = worst case num_searches*218+2 when that fits in half of the free
+                                  * HBM (no position can overflow), else what fits, at least num_searches*64+256 */
     int32_t planes_dtype;        /* SZ_PLANES_F32 / SZ_PLANES_BF16: element type of the network input */
     int32_t device;              /* HIP device ordinal */
 } sz_config;

@@ -684,7 +684,20 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
     memset(&v, 0, sizeof v);
     v.B = cfg->n_boards; v.S = cfg->num_searches;
     v.n_cap = cfg->num_searches + 2;
-    v.e_cap = cfg->edges_per_board > 0 ? cfg->edges_per_board : cfg->num_searches * 64 + 256;
+    if (cfg->edges_per_board > 0) {
+        v.e_cap = cfg->edges_per_board;
+    } else {
+        // default: the worst case (every expansion creates the maximum of 218 children) when it fits in half of the free HBM, so that no
+        // position can overflow a search (4096 boards x 800 searches: 22.9 GB of the 288 GB); otherwise what fits, at least 64 per search
+        const long long worst = (long long)cfg->num_searches * SZ_MAX_MOVES + 2, floor_cap = (long long)cfg->num_searches * 64 + 256;
+        size_t free_b = 0, total_b = 0;
+        long long fit = floor_cap;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            fit = (long long)(free_b / 2 / ((size_t)cfg->n_boards * (sizeof(EdgeStat) + sizeof(EdgeMeta))));
+        long long cap = worst < fit ? worst : fit;
+        if (cap < floor_cap) cap = floor_cap;
+        v.e_cap = (int)cap;
+    }
     if (v.e_cap < SZ_MAX_CHILDREN + 2) v.e_cap = SZ_MAX_CHILDREN + 2;
     v.p_cap = cfg->num_searches + 2;
     v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
