@@ -285,13 +285,25 @@ __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uin
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// LDS byte offset (inside its image) that lane (p16, kg) reads for position tile j under tap `tap` — see conv_kloop16 for the zero region
+template <int PITCH, int NTAPS, int WGB>
+__device__ __forceinline__ int conv_tap_addr16(int tap, int j, int p16, int kg) {
+    const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
+    const int pos = (j & 3) * 16 + p16;                    // position inside its board (board = j >> 2)
+    const int y = (pos >> 3) + dy, x = (pos & 7) + dx;
+    const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
+    const int vrow = pos + 8 * dy + dx;
+    return ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
+}
+
 template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */>
 __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip, bool wprobe = false,
                                              uint4 (*ring_in)[4] = nullptr, const int img_off = 0 /* byte offset of the image inside `lds` */,
-                                             const float* __restrict__ bias = nullptr /* accumulators start at the bias (C layout: channel = 16*tile + 4*(lane>>4) + reg) */) {
+                                             const float* __restrict__ bias = nullptr /* accumulators start at the bias (C layout: channel = 16*tile + 4*(lane>>4) + reg) */,
+                                             const int* addr_tab = nullptr /* optional LDS table [NTAPS][NJ][64] of conv_tap_addr16 values: a tap's addresses
+                                                                              are then 8 ds_read_b32 instead of ~50 VALU instructions of coordinate arithmetic */) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;             // 34 slots of 16 B per row: (2p + kg) mod 16 is a permutation per lane group
     constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
-    constexpr int ZERO_ROW = WGB * 64;
     constexpr int NI = 4, NJ = 4 * WGB, NH = NJ / 2;       // channel tiles, position tiles, position tiles per half-step
     constexpr int TOTAL_KS = NTAPS * KSTEPS;
     const int W_KSTEP_STRIDE = wprobe ? 0 : 16 * 64;       // uint4 per (tap,k32); 0 = timing probe: every k-step re-reads the same (L1-hot) fragments
@@ -317,23 +329,23 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     // the image's offset is folded into the per-lane row address, so the k offset still fits the 16-bit immediate of ds_read for the
     // second image of the persistent tower, which sits beyond 64 KB (otherwise every read pays a v_add)
     auto tap_addr = [&](int tap, int j) -> int {
-        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
-        int pos = (j & 3) * 16 + p16;                      // position inside its board (board = j >> 2)
-        int y = (pos >> 3) + dy, x = (pos & 7) + dx;
-        bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
         // Off-board taps read zeros.  ds_read_b128 is conflict-free when the 16 lanes of a group hit 16 different 16-byte slots mod 256 B;
         // a valid lane's slot is (2*row + kg + 4*kc) mod 16 and the rows of a group are consecutive, which makes that a permutation.  An
         // off-board lane therefore reads the zero region (768 B, 256-B aligned) at the slot its VIRTUAL row would have had, instead of
         // one shared zero row that collides with some valid lane's slot.
-        const int vrow = pos + 8 * ((NTAPS == 9) ? tap / 3 - 1 : 0) + dx;
-        int a = img_off + (ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : ZERO_ROW * PITCH + ((2 * vrow + kg) & 15) * 16);
+        // returned WITHOUT the image offset: a table value must not be touched where it is loaded (that would drain the LDS queue at the
+        // head of the tap); abs_addr() adds the offset where the address is first used, at the end of the tap
+        return addr_tab ? addr_tab[(tap * NJ + j) * 64 + lane] : conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
+    };
+    auto abs_addr = [&](int rel) -> int {
+        int a = img_off + rel;
         asm volatile("" : "+v"(a));                        // opaque: keeps img_off inside the VGPR (hipcc otherwise re-associates it into a per-read v_add)
         return a;
     };
     int bcur[NJ], bnxt[NJ];
     bf16x8 bfrag[2][NH];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { bcur[j] = tap_addr(0, j); bnxt[j] = bcur[j]; }
+    for (int j = 0; j < NJ; j++) { bnxt[j] = tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
 #pragma unroll
     for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
     for (int tap = 0; tap < (skip ? 0 : NTAPS); tap++) {
@@ -360,7 +372,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                         for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
                     } else if (tap + 1 < NTAPS) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bnxt[j]);
+                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + abs_addr(bnxt[j]));
                     }
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
@@ -379,7 +391,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                                 if (ABL & 2) {}
                                 else if (hs == 0) bfrag[1][m] = *(const bf16x8*)(lds + bcur[NH + m] + kc * 64);
                                 else if (kc + 1 < KSTEPS) bfrag[0][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
-                                else if (tap + 1 < NTAPS) bfrag[0][m] = *(const bf16x8*)(lds + bnxt[m]);
+                                else if (tap + 1 < NTAPS) bfrag[0][m] = *(const bf16x8*)(lds + abs_addr(bnxt[m]));
                             } else if (m < NH + NI) {
                                 if (ABL & 1) {}
                                 else if (hs == 0 && ks + PF < TOTAL_KS)
@@ -394,7 +406,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
             }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; j++) bcur[j] = bnxt[j];
+        for (int j = 0; j < NJ; j++) bcur[j] = abs_addr(bnxt[j]);
     }
 }
 
@@ -820,6 +832,10 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         *(uint4*)(bufX + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
         *(uint4*)(bufT + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
     }
+    // tap address table of the 256-channel images (9 taps x 8 position tiles x 64 lanes), built once per workgroup
+    int* addr_tab = (int*)(lds + 2 * IMG);
+    for (int e = threadIdx.x; e < 9 * 4 * WGB * 64; e += 256)
+        addr_tab[e] = conv_tap_addr16<NN_COUT * 2 + NN_PAD16, 9, WGB>(e / (4 * WGB * 64), (e >> 6) % (4 * WGB), e & 15, (e >> 4) & 3);
     f32x4 acc[4][4 * WGB];
     uint4 ring[4][4];                                                  // next convolution's first weight fragments, fetched under the current epilogue
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -836,14 +852,14 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         for (int blk = 0; blk < n_blocks; blk++) {
             const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
             TSTAMP(0);
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk]);
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab);
             TSTAMP(1);
             conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
             acc_to_lds16<WGB>(bufT, acc, nullptr, true);   // t = relu(bn1(conv1(x)))   (bufT is idle: last read before the barrier above)
             TSTAMP(2);
             __syncthreads();
             TSTAMP(3);
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk]);   // reads bufT
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab);   // reads bufT
             TSTAMP(4);
             if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
             acc_residual_inplace16<WGB>(bufX, acc, nullptr);   // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
@@ -998,7 +1014,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         if (!w_packed[i] || !bias[i]) return SZ_ERR_INVALID;
         prm.w[i] = (const uint4*)w_packed[i]; prm.b[i] = bias[i];
     }
-    const size_t lds = 2 * ((size_t)(2 * 64) * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16);
+    const size_t lds = 2 * ((size_t)(2 * 64) * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16) + 9 * 8 * 64 * sizeof(int);   // two images + tap address table
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
