@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 #include "../../include/sigmazero.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -310,11 +311,17 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
     const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
+    // The accumulators start at the bias: the MFMAs of the very first k-step take the bias quad as their C operand (tap 0 is peeled
+    // off the tap loop for that), so no accumulator is ever initialised separately (128 v_accvgpr writes per convolution otherwise).
+    f32x4 binit[NI];
 #pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const f32x4 b4 = bias ? *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; i++) binit[i] = bias ? *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool PEEL = RING == 4;                       // 512-register tower only: the peeled copy costs the 256-register kernels spills
+    if (skip || !PEEL) {
 #pragma unroll
-        for (int j = 0; j < NJ; j++) acc[i][j] = b4;
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
     }
     constexpr int PF = RING - 1;                           // weight prefetch distance in k-steps (512 matrix-pipe cycles each)
     static_assert(KSTEPS % RING == 0, "ring slots must be compile-time indices");
@@ -348,7 +355,8 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     for (int j = 0; j < NJ; j++) { bnxt[j] = tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
 #pragma unroll
     for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
-    for (int tap = 0; tap < (skip ? 0 : NTAPS); tap++) {
+    auto tap_body = [&](const int tap, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         if (tap + 1 < NTAPS) {
 #pragma unroll
             for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
@@ -382,7 +390,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
-                        acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], acc[i][hs * NH + j], 0, 0, 0);
+                        acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j], 0, 0, 0);
                         if (NN_ILV) {
                             // one memory instruction per MFMA gap (an MFMA leaves 8 of its 16 cycles for other issue): first the next
                             // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2)
@@ -407,6 +415,14 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++) bcur[j] = abs_addr(bnxt[j]);
+    };
+    if (!skip) {
+        if constexpr (PEEL) {
+            tap_body(0, std::true_type{});
+            for (int tap = 1; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
+        } else {
+            for (int tap = 0; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
+        }
     }
 }
 
