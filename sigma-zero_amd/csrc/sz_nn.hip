@@ -625,14 +625,14 @@ __global__ __launch_bounds__(256) void k_policy_head(const uint16_t* __restrict_
         }
 }
 
-#define VH_BOARDS_PER_WAVE 4
+template <int VH_BOARDS_PER_WAVE /* 4 at large batches (fc_v1 staging amortised over 16 boards), 1 at small ones (4x the workgroups) */>
 __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__ x, const float* __restrict__ wv, float bv, const float* __restrict__ fc1_w /*[64][256]*/,
                                                      const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, float fc2_b, float* __restrict__ value, int n_boards,
                                                      const float* __restrict__ v1_in /* optional: relu(bn(conv_v1)) [n_boards][64] from k_heads16_bf16 */) {
     // workgroup = 4 waves x 4 boards each; fc_v1's 64 KB weight matrix is staged in LDS once per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char vh_lds[];
     float* w1s = (float*)vh_lds;                            // [64][256]
-    float* v1s = w1s + 64 * 256;                            // [4 waves][64]
+    float* v1s = w1s + 64 * 256;                            // [4 waves][4 boards][64] (direct-x mode uses [4 waves][64])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < 64 * 256 / 4; c += 256) ((float4*)w1s)[c] = ((const float4*)fc1_w)[c];
     float wreg[8], b1r[4], w2r[4];
@@ -641,6 +641,43 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; q++) { b1r[q] = fc1_b[lane + 64 * q]; w2r[q] = fc2_w[lane + 64 * q]; }
     __syncthreads();
+    if (v1_in) {
+        // conv_v1 outputs given (fused heads kernel): the wave's 4 boards go through fc_v1 together, so every weight read from LDS
+        // serves 4 boards
+        const int board0 = (blockIdx.x * 4 + wave) * VH_BOARDS_PER_WAVE;
+        if (board0 >= n_boards) return;
+        float* vw = v1s + wave * (VH_BOARDS_PER_WAVE * 64);
+#pragma unroll
+        for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++) vw[bi * 64 + lane] = (board0 + bi < n_boards) ? v1_in[(size_t)(board0 + bi) * 64 + lane] : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the wave's own LDS writes have landed
+        float h[VH_BOARDS_PER_WAVE][4];
+#pragma unroll
+        for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[bi][q] = b1r[q];
+#pragma unroll 4
+        for (int p = 0; p < 64; p++) {
+            float w[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = w1s[p * 256 + lane + 64 * q];
+#pragma unroll
+            for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++) {
+                const float vp = vw[bi * 64 + p];
+#pragma unroll
+                for (int q = 0; q < 4; q++) h[bi][q] += vp * w[q];
+            }
+        }
+#pragma unroll
+        for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++) {
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) part += fmaxf(h[bi][q], 0.f) * w2r[q];
+            for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0 && board0 + bi < n_boards) value[board0 + bi] = tanhf(part + fc2_b);
+        }
+        return;
+    }
     for (int bi = 0; bi < VH_BOARDS_PER_WAVE; bi++) {
         const int board = (blockIdx.x * 4 + wave) * VH_BOARDS_PER_WAVE + bi;
         if (board >= n_boards) break;
@@ -1066,14 +1103,14 @@ int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bia
 int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
                           float* value, int32_t n_boards, void* stream) {
     if (!x || !wv || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
-    const size_t lds = (64 * 256 + 4 * 64) * sizeof(float);
+    const size_t lds = (64 * 256 + 16 * 64) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_value_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int per_wg = 4 * VH_BOARDS_PER_WAVE;
-    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards, (const float*)nullptr);
+    const int per_wg = 4 * 4;
+    hipLaunchKernelGGL(k_value_head<4>, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards, (const float*)nullptr);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
@@ -1083,19 +1120,23 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
                      const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch,
                      int32_t n_boards, int32_t do_softmax, void* stream) {
     if (!x || !w_p1_packed || !b_p1 || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0) return SZ_ERR_INVALID;
-    const size_t lds_h = (size_t)(2 * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16 + 64, lds_v = (64 * 256 + 4 * 64) * sizeof(float);
+    const size_t lds_h = (size_t)(2 * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16 + 64, lds_v = (64 * 256 + 16 * 64) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-        HIPCHK(hipFuncSetAttribute((const void*)k_value_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_heads16_bf16, dim3((n_boards + 1) / 2), dim3(256), lds_h, (hipStream_t)stream, (const uint16_t*)x, (const uint4*)w_p1_packed, b_p1,
                        (const uint4*)w_p2_packed, b_p2, wv, bv, probs, v1_scratch, n_boards, do_softmax);
     HIPCHK(hipGetLastError());
-    const int per_wg = 4 * VH_BOARDS_PER_WAVE;
-    hipLaunchKernelGGL(k_value_head, dim3((n_boards + per_wg - 1) / per_wg), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b,
-                       value, n_boards, (const float*)v1_scratch);
+    if (n_boards > 2048)
+        hipLaunchKernelGGL(k_value_head<4>, dim3((n_boards + 15) / 16), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b,
+                           value, n_boards, (const float*)v1_scratch);
+    else
+        hipLaunchKernelGGL(k_value_head<1>, dim3((n_boards + 3) / 4), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b,
+                           value, n_boards, (const float*)v1_scratch);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
