@@ -12,9 +12,12 @@ classical-chess boards per GPU, num_searches=800, bf16 policy/value network with
 Boards are independent, so with N ranks each rank owns 4096 boards (weak scaling, no data-path collective).
 
 One JSON line is printed by rank 0.  Extra objects:
-  roofline      the hand-written HIP kernel that does the tree work (k_search_step), HBM-bound:
-                algorithmic bytes per launch / measured mean launch duration (HIP events on the launch stream)
-  roofline_nn   the policy/value network forward (MFMA-bound): 2.915 GFLOP x boards / mean forward duration
+  roofline      the dominant kernel of the job (97.7 % of GPU time): k_tower16_bf16, the whole policy/value tower in one persistent
+                MFMA launch — algorithmic FLOP per launch / mean launch duration measured with HIP events on the launch stream over
+                the timed region, against the 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch from the committed
+                rocprofv3 --pmc passes (profiles/pmc_tower_latest.json)
+  roofline_tree the hand-written tree kernel (k_search_step), HBM roofline: algorithmic bytes per launch / mean launch duration
+  roofline_nn   the whole network forward (tower + heads): 2.915 GFLOP x boards / mean forward duration
   cpu_baseline  the oracle (reference algorithm restated on the CPU: one leaf per step, per-game pointer tree,
                 batch-1 fp32 forward on the host cores), timed on rank 0 over a bounded sample
 """

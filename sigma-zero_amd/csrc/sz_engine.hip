@@ -21,7 +21,8 @@
 //   * expand: masked renormalise with a fixed summation order (lane-strided partials + xor butterfly),
 //     bit-identical to oracle/oc_mcts.c; backprop: the descent path sits in LDS, one lane per level,
 //     no atomics (one leaf per board per step) => bitwise deterministic;
-//   * encode: history bitboards staged in LDS, every lane emits one 8-cell row per store (16/32 B).
+//   * encode: history bitboards staged in LDS; NCHW f32/bf16 (one 8-cell row per lane per store), NHWC bf16, or the
+//     bit-packed NHWC image of 1 KiB per board (one 16-byte store per lane) that the MFMA stem expands itself.
 // No MFMA here by design: this is latency/HBM-bound integer work; the network is the MFMA consumer.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

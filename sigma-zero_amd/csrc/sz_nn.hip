@@ -1,9 +1,14 @@
-// sz_nn.hip — hand-written CDNA4 MFMA convolutions for the policy/value tower of the reference
-// (/root/reference/network.py:36-83 BasicBlock, :105-137 policyNN stem/tower).
+// sz_nn.hip — hand-written CDNA4 MFMA kernels for the policy/value network of the reference
+// (/root/reference/network.py:36-83 BasicBlock, :105-137 policyNN stem/tower, :141-174 heads).
 //
-//   k_conv_bf16   one fused layer : conv3x3(pad 1) / conv1x1 + folded BatchNorm + bias (+ residual) (+ ReLU)
-//   k_block_bf16  one fused BasicBlock : relu(bn2(conv2(relu(bn1(conv1(x))))) + x), the intermediate activation
+//   k_tower16_bf16  THE SHIPPED PATH: stem + all BasicBlocks in one persistent launch (16x16x32 MFMA; one workgroup per CU takes
+//                   2-board tiles through all 39 convolutions with the activations resident in LDS) — see its own header below
+//   k_heads16_bf16  both heads from one read of the tower output (+ k_value_head for the 64->256->1 MLP)
+//   building blocks / cross-checks, per-layer launches:
+//   k_conv_bf16, k_conv16_bf16    one fused layer : conv3x3(pad 1) / conv1x1 + folded BatchNorm + bias (+ residual) (+ ReLU)
+//   k_block_bf16, k_block16_bf16  one fused BasicBlock : relu(bn2(conv2(relu(bn1(conv1(x))))) + x), the intermediate activation
 //                 never leaves the CU (it is written to LDS in exactly the layout the second conv reads)
+// The notes below describe the first (32x32x16) per-layer kernels; the 16x16x32 path has its own section further down.
 // NHWC bf16 in/out, f32 accumulate, C_out = 256, C_in in {128 (zero-padded 119-plane stem), 256}; one launch
 // replaces MIOpen's igemm + batch_norm + clamp + add kernels of the torch graph.
 //

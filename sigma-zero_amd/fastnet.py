@@ -1,10 +1,12 @@
-"""Inference form of policyNN (network.py) on the hand-written CDNA4 MFMA convolution (csrc/sz_nn.hip).
+"""Inference form of policyNN (network.py) on the hand-written CDNA4 MFMA kernels (csrc/sz_nn.hip).
 
-BatchNorm (eval mode) is folded into the convolution weights and a per-channel bias; every tower layer is ONE
-launch of `sz_nn_conv_bf16` (conv + bias + optional residual + ReLU, NHWC bf16, f32 accumulate).  The 39 tower
-convolutions and conv_p1 run on the custom kernel; the two tiny heads (256->73 1x1, value MLP) stay in torch.
+BatchNorm (eval mode) is folded into the convolution weights and a per-channel bias.  A forward is two-three launches:
+`sz_nn_tower_bf16` (stem + all BasicBlocks in one persistent kernel, activations resident in LDS) and `sz_nn_heads_bf16`
+(conv_p1 -> conv_p2 -> softmax and conv_v1 -> value MLP from one read of the tower output).  The per-layer entry points
+(`sz_nn_conv_bf16`, `sz_nn_block_bf16`, separate head kernels, the torch heads) stay selectable as cross-checks:
+`persistent_max_boards`, `fuse_blocks`, `fused_heads`, `native_heads`, `mfma16`.
 Input: the engine's NHWC planes [B, 64, 128] bf16 (119 real channels, the rest zero), or the same image bit-packed
-([B, 1024] uint8, engine planes_dtype="bits128"), which the stem kernel expands while staging its LDS tile.
+([B, 1024] uint8, engine planes_dtype="bits128"), which the stem expands while staging its LDS tile.
 """
 import ctypes as C
 
