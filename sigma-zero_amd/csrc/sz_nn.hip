@@ -862,8 +862,10 @@ __device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, cons
 // block-internal activation t live in two LDS images (2 x 70 KB), so between the NHWC planes read by the stem and the
 // tower output nothing but WEIGHTS moves: no per-layer tile loads/stores (5 GB of HBM traffic per forward at B=4096),
 // no launch boundaries, the residual is added in f32 from LDS.  With the whole register file per wave the weight ring is
-// 4 deep (3 k-steps = 1536 matrix-pipe cycles ahead).  Measured: wins at small batches (B=512: 1.02 vs 1.20 ms per forward),
-// loses 2 % to the per-block kernels at B=4096 (an 8-wave, two-waves-per-SIMD variant lost 7 %): FastPolicyNet picks by batch size.
+// 4 deep (3 k-steps = 1536 matrix-pipe cycles ahead), tap addresses come from a table in LDS, the first MFMAs of a convolution take
+// the bias as their C operand.  In-kernel phase timing (tools/tower_stamps.py): 91.4k cycles per BasicBlock against 73.7k MFMA cycles
+// = 80.7 % matrix-pipe busy; forward at B = 4096 7.3-7.6 ms vs 7.6-7.8 ms with per-block launches on the same box, B = 512 0.96 vs
+// 1.23 ms (an 8-wave, two-waves-per-SIMD variant lost 7 %).  FastPolicyNet uses it at every batch size.
 // =================================================================================================================
 #define NN_MAX_CONVS 40
 struct TowerParams {
