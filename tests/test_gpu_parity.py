@@ -571,3 +571,14 @@ def test_root_dirichlet_option_is_root_only_and_exact():
     k = int(n_child[0])
     assert abs(float(prior[0, :k].sum()) - (0.75 + 0.25 * k * NOISE_REFERENCE)) < 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("c960", [False, True])
+def test_many_random_positions_movegen_planes_and_first_expansions(c960):
+    """breadth instead of depth: 640 positions reached by random playouts of up to 150 plies (captures, promotions, castling, en passant,
+    repetition windows, long games), each searched for 3 simulations in lock-step with the oracle: root and first leaves' planes, legal
+    masks, child order, priors and value sums bit-exact"""
+    rng = random.Random(77 + int(c960))
+    boards = [Mirror(c960=c960, scharnagl=rng.randrange(960) if c960 else 518, pre_moves=rng.randrange(0, 150), rng=rng) for _ in range(640)]
+    st = lockstep_search(boards, 3, True, random_evaluator(5 + int(c960)), c960=c960)
+    assert st["expansions"] + st["terminal_hits"] >= 640
