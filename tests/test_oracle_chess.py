@@ -8,13 +8,13 @@ import pytest
 from oracle import oracle as O
 
 PERFT = [
-    ("startpos", None, False, [20, 400, 8902, 197281]),
-    ("kiwipete", "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", False, [48, 2039, 97862]),
-    ("pos3", "8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1", False, [14, 191, 2812, 43238, 674624]),
-    ("pos4", "r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1", False, [6, 264, 9467, 422333]),
-    ("pos5", "rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8", False, [44, 1486, 62379]),
-    ("pos6", "r4rk1/1pp1qppp/p1np1n2/2b1p1B1/2B1P1b1/P1NP1N2/1PP1QPPP/R4RK1 w - - 0 10", False, [46, 2079, 89890]),
-    ("c960", "bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9", True, [21, 528, 12189, 326672]),
+    ("startpos", None, False, [20, 400, 8902, 197281, 4865609]),
+    ("kiwipete", "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", False, [48, 2039, 97862, 4085603]),
+    ("pos3", "8/2p5/3p4/KP5r/1R3p1k/8/4P1P1/8 w - - 0 1", False, [14, 191, 2812, 43238, 674624, 11030083]),
+    ("pos4", "r3k2r/Pppp1ppp/1b3nbN/nP6/BBP1P3/q4N2/Pp1P2PP/R2Q1RK1 w kq - 0 1", False, [6, 264, 9467, 422333, 15833292]),
+    ("pos5", "rnbq1k1r/pp1Pbppp/2p5/8/2B5/8/PPP1NnPP/RNBQK2R w KQ - 1 8", False, [44, 1486, 62379, 2103487]),
+    ("pos6", "r4rk1/1pp1qppp/p1np1n2/2b1p1B1/2B1P1b1/P1NP1N2/1PP1QPPP/R4RK1 w - - 0 10", False, [46, 2079, 89890, 3894594]),
+    ("c960", "bqnb1rkr/pp3ppp/3ppn2/2p5/5P2/P2P4/NPP1P1PP/BQ1BNRKR w HFhf - 2 9", True, [21, 528, 12189, 326672, 8146062]),
 ]
 
 
