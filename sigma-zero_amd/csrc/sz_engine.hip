@@ -415,36 +415,60 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         for (int i = lane; i < SZ_MASK_WORDS; i += 64) mask[i] = bp.pmask[i];
         __syncthreads();
         const float* pol = policy + (size_t)b * SZ_NUM_ACTIONS;
-        // masked sum in the fixed order: per-lane partial over planes ascending, then xor butterfly
+        // masked sum in the fixed order: per-lane partial over planes ascending, then xor butterfly.
+        // The plane loop runs in chunks of 16 whose policy values are fetched by 16 independent loads before the first is used: a
+        // load-wait-add chain per plane cost one full memory latency for each of the ~20 non-empty planes of a position.  A lane
+        // whose bit is clear adds +0.0f, which leaves a non-negative (or NaN) partial sum bitwise unchanged.
+        constexpr int PCH = 16;
         float acc = 0.0f;
-        for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
-            u64 w = mask[pl];
-            if (w == 0) continue;
-            if ((w >> lane) & 1) acc = acc + pol[pl * 64 + lane];
+        for (int base = 0; base < SZ_MASK_WORDS; base += PCH) {
+            float pv[PCH];
+#pragma unroll
+            for (int k = 0; k < PCH; k++) {
+                const int pl = base + k < SZ_MASK_WORDS ? base + k : SZ_MASK_WORDS - 1;      // clamp: the tail chunk re-reads the last plane
+                pv[k] = pol[pl * 64 + lane];                                                 // unconditional: a uniform skip of empty planes measured slower
+            }
+#pragma unroll
+            for (int k = 0; k < PCH; k++) {
+                const int pl = base + k;
+                const bool mine = pl < SZ_MASK_WORDS && ((mask[pl < SZ_MASK_WORDS ? pl : 0] >> lane) & 1);
+                acc = acc + (mine ? pv[k] : 0.0f);
+            }
         }
         const float total = wave_sum_butterfly(acc);
         const int first = n_edges;
         int kept = 0;
         const int leaf_edge = path[d];
-        for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
-            u64 w = mask[pl];
-            if (w == 0) continue;
-            bool mine = (w >> lane) & 1;
-            float p = 0.0f;
-            if (mine) p = pol[pl * 64 + lane] / total;                 // policy /= torch.sum(policy)
-            bool keep = mine && !(p == 0.0f);                          // policy.nonzero() (NaN stays)
-            u64 km = __ballot(keep);
-            if (keep) {
-                if (v.learning && !v.root_gamma) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
-                int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
-                if (slot < v.e_cap) {
-                    EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
-                    bp.es[slot] = s;
-                    EdgeMeta m; m.first = -1; m.node = -1; m.n = 0; m.action = (unsigned short)(pl * 64 + lane); m.term = 0; m.tval = 0; m.pad = 0;
-                    bp.em[slot] = m;
-                }
+        for (int base = 0; base < SZ_MASK_WORDS; base += PCH) {
+            float pv[PCH];
+#pragma unroll
+            for (int k = 0; k < PCH; k++) {
+                const int pl = base + k < SZ_MASK_WORDS ? base + k : SZ_MASK_WORDS - 1;
+                pv[k] = pol[pl * 64 + lane];
             }
-            kept += __popcll(km);
+#pragma unroll
+            for (int k = 0; k < PCH; k++) {
+                const int pl = base + k;
+                if (pl >= SZ_MASK_WORDS) break;
+                const u64 w = mask[pl];
+                if (w == 0) continue;
+                const bool mine = (w >> lane) & 1;
+                float p = 0.0f;
+                if (mine) p = pv[k] / total;                               // policy /= torch.sum(policy)
+                const bool keep = mine && !(p == 0.0f);                    // policy.nonzero() (NaN stays)
+                const u64 km = __ballot(keep);
+                if (keep) {
+                    if (v.learning && !v.root_gamma) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
+                    const int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
+                    if (slot < v.e_cap) {
+                        EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
+                        bp.es[slot] = s;
+                        EdgeMeta m; m.first = -1; m.node = -1; m.n = 0; m.action = (unsigned short)(pl * 64 + lane); m.term = 0; m.tval = 0; m.pad = 0;
+                        bp.em[slot] = m;
+                    }
+                }
+                kept += __popcll(km);
+            }
         }
         if (first + kept > v.e_cap) { err = SZ_ERR_CAPACITY; kept = 0; }
         if (v.learning && v.root_gamma && d == 0 && kept > 0) {
