@@ -131,6 +131,10 @@ int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t*
  * the reference behaviour (mcts.py:91-98: the constant noise_value at every expansion).  Needs learning = 1. */
 int sz_set_root_noise(sz_engine* e, const float* gamma_dev);
 
+/* diagnostic only: with a device buffer of n_boards*8 uint64, sz_search_step records s_memtime at its phase boundaries per board
+ * (0 start, 1 after expand+backprop, 2 after select, 3 after move/movegen/repetition/terminal, 4 after encode); NULL = off (default) */
+int sz_debug_step_stamps(sz_engine* e, void* dev_buffer);
+
 /* test / debug readback of the pending leaves: legal-move mask [n_boards,73] uint64 (bit v of word p =
  * action p*64+v), leaf depth, node count, edge count, status per board (host pointers, may be NULL). */
 int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges,
@@ -207,6 +211,7 @@ uint64_t szh_perft(szh_game* g, int depth);
 void szh_bitboards(const szh_game* g, uint64_t* out10);
 int  szh_export(const szh_game* g, void* ring_out, int32_t* ply, int32_t* chess960);
 int  szh_is_chess960(const szh_game* g);
+int  szh_plane_bits_mismatches(const szh_game* g);                   /* test hook: kernels' bit-parallel mask extraction vs its definition; 0 = identical */
 
 #ifdef __cplusplus
 }

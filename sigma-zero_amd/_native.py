@@ -50,6 +50,7 @@ EXPORTS = {
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_policy_head_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_void_p]),
+    "sz_debug_step_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sz_set_root_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sz_nn_debug_tower_stamps": (C.c_int, [C.c_void_p, C.c_int32]),
     "sz_nn_heads_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int32] * 2 + [C.c_void_p]),
@@ -75,6 +76,7 @@ EXPORTS = {
     "szh_bitboards": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "szh_export": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "szh_is_chess960": (C.c_int, [C.c_void_p]),
+    "szh_plane_bits_mismatches": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

@@ -301,6 +301,59 @@ SZ_HD bool sz_lane_plane_bit(u64 T, bool is_pawn, int v, int plane, int white) {
     return (T >> tsq) & 1;
 }
 
+// All 73 action-plane bits of the piece on view square v at once (the bit-parallel form of sz_lane_plane_bit, which stays as the
+// definition and is what tests compare against).  q[d] bit k-1 = plane d*7+k-1 (direction d, distance k); kn bit d = plane 56+d;
+// up bit m = planes 64+m, 67+m, 70+m (knight / bishop / rook promotion share the geometry).
+// The legal-target set is brought into view coordinates (bit p = view square p); the four orientations {T, bit-reversed, byte-swapped,
+// rank-mirrored} are the view board, its 180-degree rotation, its file mirror and the mirror's rotation in an order that depends on
+// the side to move, so every ray becomes a +1, +8 or +9 walk from the lane's own (possibly transformed) index: a shift by the index,
+// a ray mask and a shift-fold that gathers every 8th / 9th bit into 7 consecutive ones.  ~130 vector instructions per lane replace
+// 73 evaluations of the coordinate arithmetic (~2,500).
+struct SzPlaneBits { uint32_t q[8]; uint32_t kn, up; };
+SZ_HD uint32_t sz_fold9(u64 x) { x &= 0x0040201008040201ULL; x |= x >> 8; x |= x >> 16; x |= x >> 32; return (uint32_t)x & 0x7Fu; }   // bits 9j -> j
+SZ_HD uint32_t sz_fold8(u64 x) { x &= 0x0001010101010101ULL; x |= x >> 7; x |= x >> 14; x |= x >> 28; return (uint32_t)x & 0x7Fu; }   // bits 8j -> j
+SZ_HD uint32_t sz_low_mask(int n) { return (1u << n) - 1u; }                                          // n in 0..7
+SZ_HD SzPlaneBits sz_lane_plane_bits(u64 T, bool is_pawn, int v, int white) {
+    SzPlaneBits o;
+    const u64 R = sz_brev(T), S = __builtin_bswap64(T), Mi = __builtin_bswap64(R);
+    const u64 Tv = white ? S : Mi;         // view board: bit p = real square p ^ sz_view_flip(white)
+    const u64 Tr = white ? Mi : S;         // rotated by 180 degrees (index 63 - p)
+    const u64 Tm = white ? R : T;          // files mirrored (index p ^ 7)
+    const u64 Tmr = white ? T : R;         // mirrored and rotated
+    const int row = v >> 3, col = v & 7, vm = v ^ 7;
+    const u64 A = Tv >> v, B = Tr >> (63 - v), C = Tm >> vm, D = Tmr >> (63 - vm);
+    const int e = 7 - col, sth = 7 - row;
+    o.q[2] = (uint32_t)(A >> 1) & sz_low_mask(e);                                   // (+1, 0)  right
+    o.q[6] = (uint32_t)(B >> 1) & sz_low_mask(col);                                 // (-1, 0)  left
+    o.q[4] = sz_fold8(A >> 8);                                                      // ( 0,+1)  down
+    o.q[0] = sz_fold8(B >> 8);                                                      // ( 0,-1)  up
+    o.q[3] = sz_fold9(A >> 9) & sz_low_mask(e < sth ? e : sth);                     // (+1,+1)
+    o.q[7] = sz_fold9(B >> 9) & sz_low_mask(col < row ? col : row);                 // (-1,-1)
+    o.q[5] = sz_fold9(C >> 9) & sz_low_mask(col < sth ? col : sth);                 // (-1,+1) = (+1,+1) on the mirrored board
+    o.q[1] = sz_fold9(D >> 9) & sz_low_mask(e < row ? e : row);                     // (+1,-1) = (-1,-1) on the mirrored board
+    // knight jumps d = 0..7: (dc,dr) = (1,-2),(2,-1),(2,1),(1,2),(-1,2),(-2,1),(-2,-1),(-1,-2); the constants hold the view squares
+    // from which jump d stays on the board
+    uint32_t kn = 0;
+    kn |= (uint32_t)((Tv >> ((v - 15) & 63)) & (0x7f7f7f7f7f7f0000ULL >> v) & 1) << 0;
+    kn |= (uint32_t)((Tv >> ((v - 6) & 63)) & (0x3f3f3f3f3f3f3f00ULL >> v) & 1) << 1;
+    kn |= (uint32_t)((Tv >> ((v + 10) & 63)) & (0x003f3f3f3f3f3f3fULL >> v) & 1) << 2;
+    kn |= (uint32_t)((Tv >> ((v + 17) & 63)) & (0x00007f7f7f7f7f7fULL >> v) & 1) << 3;
+    kn |= (uint32_t)((Tv >> ((v + 15) & 63)) & (0x0000fefefefefefeULL >> v) & 1) << 4;
+    kn |= (uint32_t)((Tv >> ((v + 6) & 63)) & (0x00fcfcfcfcfcfcfcULL >> v) & 1) << 5;
+    kn |= (uint32_t)((Tv >> ((v - 10) & 63)) & (0xfcfcfcfcfcfcfc00ULL >> v) & 1) << 6;
+    kn |= (uint32_t)((Tv >> ((v - 17) & 63)) & (0xfefefefefefe0000ULL >> v) & 1) << 7;
+    o.kn = kn;
+    // under-promotions: a pawn on view row 1 stepping onto row 0 straight / to the right / to the left
+    uint32_t up = 0;
+    if (is_pawn && row == 1) {
+        const uint32_t t2 = (uint32_t)(Tv >> ((v - 8) & 63)) & 3u;                  // bit 0: v-8 (straight), bit 1: v-7 (right)
+        const uint32_t tl = (uint32_t)(Tv >> ((v - 9) & 63)) & 1u;                  // v-9 (left)
+        up = (t2 & 1u) | ((col < 7 ? t2 >> 1 : 0u) << 1) | ((col > 0 ? tl : 0u) << 2);
+    }
+    o.up = up;
+    return o;
+}
+
 // move -> action index.  promo: 0 none / SZ_N / SZ_B / SZ_R / SZ_Q
 SZ_HD int sz_action_index(int from, int to, int promo, int white) {
     int f = from ^ sz_view_flip(white), t = to ^ sz_view_flip(white);

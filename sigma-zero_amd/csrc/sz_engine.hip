@@ -50,6 +50,7 @@ struct alignas(16) Ctl {
 struct View {
     int B, S, n_cap, e_cap, p_cap, learning, chess960, planes_dtype;
     float c_puct, noise;
+    unsigned long long* dbg;    // diagnostic (sz_debug_step_stamps): 8 u64 per board, s_memtime at the phase boundaries of k_search_step; NULL = off
     const float* root_gamma;    // optional (non-reference) true Dirichlet root noise: [B][SZ_MAX_MOVES] Gamma(alpha,1) draws; NULL = reference behaviour
     SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
     // per-ply training record
@@ -144,10 +145,14 @@ __device__ void wave_movegen(const SzPos& X, int chess960, u64* mask_lds, int& n
     const bool is_pawn = (X.pc[SZ_P] >> s) & 1;
     int ep = szm_ep(X.meta);
     ep_legal = (ep >= 0) ? (__ballot(is_pawn && ((T >> ep) & 1)) != 0) : 0;
+    // legal-move mask in action-index order (chess_tensor.py:190-218): 73 ballots over the lane's plane bits (sz_lane_plane_bits)
+    const SzPlaneBits pb = sz_lane_plane_bits(T, is_pawn, lane, I.white);
     int n = 0;
+#pragma unroll
     for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
-        bool bit = T && sz_lane_plane_bit(T, is_pawn, lane, pl, I.white);
-        u64 w = __ballot(bit);
+        const uint32_t word = pl < 56 ? pb.q[pl / 7] : (pl < 64 ? pb.kn : pb.up);
+        const int sh = pl < 56 ? pl % 7 : (pl < 64 ? pl - 56 : (pl - 64) % 3);
+        const u64 w = __ballot((word >> sh) & 1u);
         if (lane == 0) mask_lds[pl] = w;
         n += __popcll(w);
     }
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
 // kernel: one lock-step iteration (expand + backprop of the evaluated leaf, then select / move /
 // terminal test / encode of the next one)
 // ------------------------------------------------------------------------------------------------
+#define STEP_STAMP(k) do { if (v.dbg) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) v.dbg[(size_t)blockIdx.x * 8 + (k)] = _t; } } while (0)
 __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restrict__ policy, const float* __restrict__ value, void* planes) {
     extern __shared__ u64 lds64[];
     u64* hist = lds64; u64* mask = lds64 + LDS_HIST_WORDS; int* path = (int*)(lds64 + LDS_HIST_WORDS + LDS_MASK_WORDS);
@@ -407,6 +413,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
     const int root_ply = uni(bp.ctl->game_ply);
     unsigned long long n_expand = 0, n_term = 0, sum_depth = 0, sum_k = 0;
     int err = 0;
+    STEP_STAMP(0);
 
     if (status & ST_PENDING) {
         // ---- mcts.py:77-109 for the leaf evaluated by the network -------------------------------
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         sims++; n_expand++; sum_depth += d; sum_k += kept;
         status &= ~ST_PENDING;
     }
+    STEP_STAMP(1);
 
     // ---- next simulation(s): mcts.py:49-64 ------------------------------------------------------
     while (sims < v.S && !err) {
@@ -519,6 +527,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
             m.first = uni(m.first); mn = uni((int)m.n);
         }
         if (err) break;
+        STEP_STAMP(2);
         int node = uni(m.node);
         if (node >= 0) {
             // visited leaf without children: a terminal position (mcts.py:104-109)
@@ -532,6 +541,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         const int parent_node = uni(bp.em[path[d - 1]].node);
         SzPos P = load_pos(bp.npos + parent_node);
         SzPos X = wave_create_position(bp, P, (int)uni((int)m.action), v.chess960, path, d, root_ply, mask);
+        STEP_STAMP(3);
         const int nid = n_nodes++;
         const int is_term = szm_term(X.meta);
         if (lane == 0) {
@@ -555,6 +565,7 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         wave_encode(hist, X, (char*)planes + (size_t)b * planes_board_bytes(v.planes_dtype), v.planes_dtype, nullptr);
         status |= ST_PENDING;
         if (lane == 0) { bp.ctl->pend_node = nid; bp.ctl->pend_depth = d; }
+        STEP_STAMP(4);
         break;
     }
     if (sims >= v.S && !(status & ST_PENDING)) status |= ST_DONE;
@@ -726,7 +737,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
     if (v.e_cap < SZ_MAX_CHILDREN + 2) v.e_cap = SZ_MAX_CHILDREN + 2;
     v.p_cap = cfg->num_searches + 2;
     v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
-    v.c_puct = cfg->c_puct; v.noise = cfg->noise_value; v.root_gamma = nullptr;
+    v.c_puct = cfg->c_puct; v.noise = cfg->noise_value; v.root_gamma = nullptr; v.dbg = nullptr;
     e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4;
     if (e->lds_bytes > 64 * 1024) { delete e; return SZ_ERR_INVALID; }
     const size_t B = v.B;
@@ -767,6 +778,12 @@ int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, 
     HIPCHK(hipStreamSynchronize(s));                    // host staging buffers go out of scope
     hipLaunchKernelGGL(k_new_games, dim3(e->v.B), dim3(64), e->lds_bytes, s, e->v, e->d_scharnagl, active ? e->d_active : nullptr);
     HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+int sz_debug_step_stamps(sz_engine* e, void* dev_buffer) {
+    if (!e) return SZ_ERR_INVALID;
+    e->v.dbg = (unsigned long long*)dev_buffer;
     return SZ_OK;
 }
 

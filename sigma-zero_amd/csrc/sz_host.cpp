@@ -275,4 +275,27 @@ int szh_export(const szh_game* g, void* ring_out /* SZ_RING * 80 bytes */, int32
 
 int szh_is_chess960(const szh_game* g) { return g->chess960; }
 
+// test hook: the bit-parallel plane extraction the kernels use (sz_lane_plane_bits) against its definition (sz_lane_plane_bit) on the
+// current position's legal-target sets; returns the number of differing (view square, plane) pairs (0 = identical)
+int szh_plane_bits_mismatches(const szh_game* g) {
+    const SzPos& p = g->ring[g->ply & (SZ_RING - 1)];
+    Gen gen;
+    generate(p, g->chess960, gen);
+    const int white = szm_turn(p.meta), flip = sz_view_flip(white);
+    int bad = 0;
+    for (int v = 0; v < 64; v++) {
+        const int s = v ^ flip;
+        const u64 T = gen.targets[s];
+        const bool is_pawn = (p.pc[SZ_P] >> s) & 1;
+        const SzPlaneBits pb = sz_lane_plane_bits(T, is_pawn, v, white);
+        for (int pl = 0; pl < SZ_MASK_WORDS; pl++) {
+            const uint32_t word = pl < 56 ? pb.q[pl / 7] : (pl < 64 ? pb.kn : pb.up);
+            const int sh = pl < 56 ? pl % 7 : (pl < 64 ? pl - 56 : (pl - 64) % 3);
+            const bool fast = (word >> sh) & 1u, ref = T && sz_lane_plane_bit(T, is_pawn, v, pl, white);
+            bad += fast != ref;
+        }
+    }
+    return bad;
+}
+
 }  // extern "C"
