@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
 // terminal test / encode of the next one)
 // ------------------------------------------------------------------------------------------------
 #define STEP_STAMP(k) do { if (v.dbg) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) v.dbg[(size_t)blockIdx.x * 8 + (k)] = _t; } } while (0)
-__global__ __launch_bounds__(64) void k_search_step(View v, const float* __restrict__ policy, const float* __restrict__ value, void* planes) {
+__global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __restrict__ policy, const float* __restrict__ value, void* planes) {
     extern __shared__ u64 lds64[];
     u64* hist = lds64; u64* mask = lds64 + LDS_HIST_WORDS; int* path = (int*)(lds64 + LDS_HIST_WORDS + LDS_MASK_WORDS);
     const int b = blockIdx.x, lane = lane_id();
@@ -423,59 +423,69 @@ __global__ __launch_bounds__(64) void k_search_step(View v, const float* __restr
         __syncthreads();
         const float* pol = policy + (size_t)b * SZ_NUM_ACTIONS;
         // masked sum in the fixed order: per-lane partial over planes ascending, then xor butterfly.
-        // The plane loop runs in chunks of 16 whose policy values are fetched by 16 independent loads before the first is used: a
-        // load-wait-add chain per plane cost one full memory latency for each of the ~20 non-empty planes of a position.  A lane
-        // whose bit is clear adds +0.0f, which leaves a non-negative (or NaN) partial sum bitwise unchanged.
+        // Only planes that hold a legal move are fetched (~20 of 73), and in groups of 16 INDEPENDENT loads: a load-wait-add chain per
+        // plane cost one full memory latency each, and fetching all 73 planes made the kernel bandwidth-bound at 4096 boards.  The
+        // value and action of every legal move are stashed in LDS in ascending action order, so the second half works on the K <= 218
+        // children directly (lane = child: coalesced child records) instead of walking the planes again.
+        const int path_alloc = v.p_cap > 256 ? v.p_cap : 256;
+        float* sval = (float*)(path + path_alloc);                          // [<= 218] policy value of legal move c
+        unsigned short* sact = (unsigned short*)(sval + 220);               // [<= 218] its action index
+        u64 ne0 = __ballot(mask[lane] != 0);                                // planes 0..63 with at least one legal move
+        u64 ne1 = __ballot(lane < SZ_MASK_WORDS - 64 && mask[64 + (lane < SZ_MASK_WORDS - 64 ? lane : 0)] != 0);   // planes 64..72
         constexpr int PCH = 16;
         float acc = 0.0f;
-        for (int base = 0; base < SZ_MASK_WORDS; base += PCH) {
+        int n_moves = 0;
+        while (ne0 | ne1) {
+            int pls[PCH];
+#pragma unroll
+            for (int k = 0; k < PCH; k++) {                                  // next PCH non-empty planes, ascending (uniform)
+                int pl = -1;
+                if (ne0) { pl = __builtin_ctzll(ne0); ne0 &= ne0 - 1; }
+                else if (ne1) { pl = 64 + __builtin_ctzll(ne1); ne1 &= ne1 - 1; }
+                pls[k] = pl;
+            }
             float pv[PCH];
 #pragma unroll
-            for (int k = 0; k < PCH; k++) {
-                const int pl = base + k < SZ_MASK_WORDS ? base + k : SZ_MASK_WORDS - 1;      // clamp: the tail chunk re-reads the last plane
-                pv[k] = pol[pl * 64 + lane];                                                 // unconditional: a uniform skip of empty planes measured slower
-            }
+            for (int k = 0; k < PCH; k++) pv[k] = pol[(pls[k] >= 0 ? pls[k] : 0) * 64 + lane];     // issued back to back; plane 0 stands in for "none"
 #pragma unroll
             for (int k = 0; k < PCH; k++) {
-                const int pl = base + k;
-                const bool mine = pl < SZ_MASK_WORDS && ((mask[pl < SZ_MASK_WORDS ? pl : 0] >> lane) & 1);
-                acc = acc + (mine ? pv[k] : 0.0f);
+                const int pl = pls[k];
+                if (pl >= 0) {                                               // uniform
+                    const bool mine = (mask[pl] >> lane) & 1;
+                    if (mine) acc = acc + pv[k];
+                    const u64 mm = __ballot(mine);
+                    if (mine) {
+                        const int r = n_moves + __popcll(mm & ((1ULL << lane) - 1));
+                        sval[r] = pv[k];
+                        sact[r] = (unsigned short)(pl * 64 + lane);
+                    }
+                    n_moves += __popcll(mm);
+                }
             }
         }
         const float total = wave_sum_butterfly(acc);
+        __syncthreads();                                                     // one wave per workgroup: makes the LDS stash visible
         const int first = n_edges;
         int kept = 0;
         const int leaf_edge = path[d];
-        for (int base = 0; base < SZ_MASK_WORDS; base += PCH) {
-            float pv[PCH];
-#pragma unroll
-            for (int k = 0; k < PCH; k++) {
-                const int pl = base + k < SZ_MASK_WORDS ? base + k : SZ_MASK_WORDS - 1;
-                pv[k] = pol[pl * 64 + lane];
-            }
-#pragma unroll
-            for (int k = 0; k < PCH; k++) {
-                const int pl = base + k;
-                if (pl >= SZ_MASK_WORDS) break;
-                const u64 w = mask[pl];
-                if (w == 0) continue;
-                const bool mine = (w >> lane) & 1;
-                float p = 0.0f;
-                if (mine) p = pv[k] / total;                               // policy /= torch.sum(policy)
-                const bool keep = mine && !(p == 0.0f);                    // policy.nonzero() (NaN stays)
-                const u64 km = __ballot(keep);
-                if (keep) {
-                    if (v.learning && !v.root_gamma) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
-                    const int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
-                    if (slot < v.e_cap) {
-                        EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
-                        bp.es[slot] = s;
-                        EdgeMeta m; m.first = -1; m.node = -1; m.n = 0; m.action = (unsigned short)(pl * 64 + lane); m.term = 0; m.tval = 0; m.pad = 0;
-                        bp.em[slot] = m;
-                    }
+        for (int base = 0; base < n_moves; base += 64) {
+            const int c = base + lane;
+            const bool mine = c < n_moves;
+            float p = 0.0f;
+            if (mine) p = sval[c] / total;                                  // policy /= torch.sum(policy)
+            const bool keep = mine && !(p == 0.0f);                         // policy.nonzero() (NaN stays)
+            const u64 km = __ballot(keep);
+            if (keep) {
+                if (v.learning && !v.root_gamma) p = (0.75f * p) + (0.25f * v.noise);   // (1-eps)*probs + eps*noise
+                const int slot = first + kept + __popcll(km & ((1ULL << lane) - 1));
+                if (slot < v.e_cap) {
+                    EdgeStat s; s.W = 0.0; s.N = 0; s.P = p;
+                    bp.es[slot] = s;
+                    EdgeMeta m; m.first = -1; m.node = -1; m.n = 0; m.action = sact[c]; m.term = 0; m.tval = 0; m.pad = 0;
+                    bp.em[slot] = m;
                 }
-                kept += __popcll(km);
             }
+            kept += __popcll(km);
         }
         if (first + kept > v.e_cap) { err = SZ_ERR_CAPACITY; kept = 0; }
         if (v.learning && v.root_gamma && d == 0 && kept > 0) {
@@ -738,7 +748,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
     v.p_cap = cfg->num_searches + 2;
     v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
     v.c_puct = cfg->c_puct; v.noise = cfg->noise_value; v.root_gamma = nullptr; v.dbg = nullptr;
-    e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4;
+    e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4 + 220 * 4 + 220 * 2;   // + expand stash
     if (e->lds_bytes > 64 * 1024) { delete e; return SZ_ERR_INVALID; }
     const size_t B = v.B;
     int rc = SZ_OK;
