@@ -302,12 +302,16 @@ __device__ __forceinline__ int conv_tap_addr16(int tap, int j, int p16, int kg) 
     return ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
 }
 
-template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */>
+template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */,
+          class EPI = std::nullptr_t /* callable (p, stage): stage -1..3 of the epilogue of accumulator tile p = i*NH + j of the FIRST position half (EpiTile16 /
+                                        EpiResidual16); when given, the LAST tap runs its two position halves one after the other and the epilogue of the first
+                                        half rides in the MFMA gaps of the second */>
 __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4 * WGB], bool skip, bool wprobe = false,
                                              uint4 (*ring_in)[4] = nullptr, const int img_off = 0 /* byte offset of the image inside `lds` */,
                                              const float* __restrict__ bias = nullptr /* accumulators start at the bias (C layout: channel = 16*tile + 4*(lane>>4) + reg) */,
                                              const int* addr_tab = nullptr /* optional LDS table [NTAPS][NJ][64] of conv_tap_addr16 values: a tap's addresses
-                                                                              are then 8 ds_read_b32 instead of ~50 VALU instructions of coordinate arithmetic */) {
+                                                                              are then 8 ds_read_b32 instead of ~50 VALU instructions of coordinate arithmetic */,
+                                             EPI epi0 = EPI()) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;             // 34 slots of 16 B per row: (2p + kg) mod 16 is a permutation per lane group
     constexpr int KSTEPS = CIN / 32;                       // k32-steps per tap
     constexpr int NI = 4, NJ = 4 * WGB, NH = NJ / 2;       // channel tiles, position tiles, position tiles per half-step
@@ -421,14 +425,139 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
         for (int j = 0; j < NJ; j++) bcur[j] = abs_addr(bnxt[j]);
     };
+    constexpr bool SPLIT = !std::is_same<EPI, std::nullptr_t>::value && NTAPS == 9 && NN_ILV && PEEL && KSTEPS % RING == 0;
+    // Last tap with its position halves in sequence (SPLIT): phase A finishes the accumulators of the first half (board 0), phase B runs the second
+    // half and carries, in two of every 16 MFMA gaps, one tile of the first half's epilogue (accumulator read-out, bf16 pack, ReLU, LDS write) —
+    // work that is otherwise exposed after the K loop.  Phase B reads the tap's weights a second time (virtual k-steps TOTAL_KS .. TOTAL_KS+KSTEPS-1
+    // of the ring); activations alternate between the two fragment buffers by k-step parity.
+    auto last_tap_split = [&]() {
+        if constexpr (SPLIT) {
+            constexpr int tap = NTAPS - 1;
+#pragma unroll
+            for (int kc = 0; kc < KSTEPS; kc++) {                            // phase A
+                const int ks = tap * KSTEPS + kc;
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
+#pragma unroll
+                    for (int j = 0; j < NH; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+                        const int m = i * NH + j;
+                        if (m < NH) {
+                            if (ABL & 2) {}
+                            else if (kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
+                            else bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m]);            // first fragments of phase B
+                        } else if (m < NH + NI) {
+                            const int vks = ks + PF, wks = vks < TOTAL_KS ? vks : vks - KSTEPS;              // phase B re-reads this tap's weights
+                            if (!(ABL & 1)) aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)wks * W_KSTEP_STRIDE + (m - NH) * 64];
+                        } else if (kc == KSTEPS - 1 && (m == 2 * NH || m == 3 * NH)) {
+                            epi0(m == 2 * NH ? 0 : 1, -1);                                                     // stage -1: operand prefetch for the first two tiles
+                        }
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int kc = 0; kc < KSTEPS; kc++) {                            // phase B
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
+#pragma unroll
+                    for (int j = 0; j < NH; j++) {
+                        acc[i][NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][NH + j], 0, 0, 0);
+                        const int m = i * NH + j;
+                        if (m < NH) {
+                            if (!(ABL & 2) && kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m] + (kc + 1) * 64);
+                        } else if (m < NH + NI) {
+                            if (!(ABL & 1) && kc + PF < KSTEPS)
+                                aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)(tap * KSTEPS + kc + PF) * W_KSTEP_STRIDE + (m - NH) * 64];
+                        } else {
+                            // 16 tiles of the first half over 8 k-steps: two per k-step, each in four stages of one or two instructions
+                            // (gaps 8..11 and 12..15), so that a gap never carries more than an MFMA leaves free
+                            const int p = 2 * kc + (m >= 3 * NH ? 1 : 0);
+                            if (p < NI * NH) epi0(p, (m - 2 * NH) & 3);
+                        }
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    };
     if (!skip) {
         if constexpr (PEEL) {
             tap_body(0, std::true_type{});
-            for (int tap = 1; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
+            for (int tap = 1; tap < (SPLIT ? NTAPS - 1 : NTAPS); tap++) tap_body(tap, std::false_type{});
+            last_tap_split();
         } else {
             for (int tap = 0; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
         }
     }
+}
+
+// Staged epilogue functors for conv_kloop16's split last tap: tile p = i*4 + j (channel tile i, position tile j of the first half) in stages
+//   -1: operand prefetch (residual only)   0: accumulator read-out   1, 2: bf16 pack (+ residual) + ReLU of one register pair each   3: LDS write
+template <int WGB> struct EpiTile16 {
+    unsigned char* img; const f32x4 (&acc)[4][4 * WGB]; f32x4 tv; uint2 o;
+    __device__ __forceinline__ EpiTile16(unsigned char* img_, const f32x4 (&acc_)[4][4 * WGB]) : img(img_), acc(acc_) {}
+    __device__ __forceinline__ void operator()(int p, int st) {
+        const int i = p / (2 * WGB), j = p % (2 * WGB);
+        if (st == 0) tv = acc[i][j];
+        else if (st == 1) o.x = relu_bf16x2(pack_bf16x2(tv[0], tv[1]));
+        else if (st == 2) o.y = relu_bf16x2(pack_bf16x2(tv[2], tv[3]));
+        else if (st == 3) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+            *(uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2) = o;
+        }
+    }
+};
+template <int WGB> struct EpiResidual16 {
+    unsigned char* img; const f32x4 (&acc)[4][4 * WGB]; f32x4 tv; uint2 o; uint2 rr[3];     // residual operands ride two tiles ahead of their use
+    __device__ __forceinline__ EpiResidual16(unsigned char* img_, const f32x4 (&acc_)[4][4 * WGB]) : img(img_), acc(acc_) {}
+    __device__ __forceinline__ uint2* slot(int p) const {
+        const int i = p / (2 * WGB), j = p % (2 * WGB);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+        return (uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2);
+    }
+    __device__ __forceinline__ void operator()(int p, int st) {
+        const int i = p / (2 * WGB), j = p % (2 * WGB);
+        if (st == -1) rr[p % 3] = *slot(p);
+        else if (st == 0) { tv = acc[i][j]; if (p + 2 < 8 * WGB) rr[(p + 2) % 3] = *slot(p + 2); }
+        else if (st == 1) o.x = relu_bf16x2(pack_bf16x2(tv[0] + bf16_lo(rr[p % 3].x), tv[1] + bf16_hi(rr[p % 3].x)));
+        else if (st == 2) o.y = relu_bf16x2(pack_bf16x2(tv[2] + bf16_lo(rr[p % 3].y), tv[3] + bf16_hi(rr[p % 3].y)));
+        else if (st == 3) *slot(p) = o;
+    }
+};
+
+// epilogue of ONE accumulator tile (channel tile i, position tile j): relu?(acc) -> bf16 -> LDS image (the accumulators started at the bias)
+template <int WGB>
+__device__ __forceinline__ void acc_tile_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], int i, int j, bool relu) {
+    constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+    const f32x4 v = acc[i][j];
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    if (relu) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
+    *(uint2*)(lds + row * OPITCH + co * 2) = o;
+}
+// the same with the residual: x <- relu(acc + x) in place on the LDS image (f32 add, one bf16 rounding)
+template <int WGB>
+__device__ __forceinline__ void acc_tile_residual16(unsigned char* xlds, const f32x4 (&acc)[4][4 * WGB], int i, int j) {
+    constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+    const f32x4 v = acc[i][j];
+    uint2* px = (uint2*)(xlds + row * OPITCH + co * 2);
+    const uint2 r = *px;
+    uint2 o;
+    o.x = relu_bf16x2(pack_bf16x2(v[0] + bf16_lo(r.x), v[1] + bf16_hi(r.x)));
+    o.y = relu_bf16x2(pack_bf16x2(v[2] + bf16_lo(r.y), v[3] + bf16_hi(r.y)));
+    *px = o;
 }
 
 // bias == nullptr: the accumulators already started at the bias (conv_kloop16's `bias` argument)
@@ -912,17 +1041,25 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         for (int blk = 0; blk < n_blocks; blk++) {
             const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
             TSTAMP(0);
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab);
+            auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB>(bufT, acc));
             TSTAMP(1);
             conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
-            acc_to_lds16<WGB>(bufT, acc, nullptr, true);   // t = relu(bn1(conv1(x)))   (bufT is idle: last read before the barrier above)
+#pragma unroll
+            for (int j = 2 * WGB; j < 4 * WGB; j++)                            // second position half; the first went out under the last tap
+#pragma unroll
+                for (int i = 0; i < 4; i++) epi_t(i, j);
             TSTAMP(2);
             __syncthreads();
             TSTAMP(3);
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab);   // reads bufT
+            auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB>(bufX, acc));   // reads bufT
             TSTAMP(4);
             if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
-            acc_residual_inplace16<WGB>(bufX, acc, nullptr);   // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+#pragma unroll
+            for (int j = 2 * WGB; j < 4 * WGB; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) epi_x(i, j);
             TSTAMP(5);
             __syncthreads();
             TSTAMP(6);
