@@ -582,3 +582,30 @@ def test_many_random_positions_movegen_planes_and_first_expansions(c960):
     boards = [Mirror(c960=c960, scharnagl=rng.randrange(960) if c960 else 518, pre_moves=rng.randrange(0, 150), rng=rng) for _ in range(640)]
     st = lockstep_search(boards, 3, True, random_evaluator(5 + int(c960)), c960=c960)
     assert st["expansions"] + st["terminal_hits"] >= 640
+
+
+def test_long_games_at_scale_finish_cleanly():
+    """stress: 768 Chess960 games played to the end (or 700 plies) with the MFMA network and 12 searches per move — history ring wrap-around
+    (> 256 plies), 75-move / repetition / material draws and mates at scale; every record stays well-formed and no board reports an error"""
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    from sigma_zero_amd.sim import play_games
+    torch.manual_seed(1)
+    np.random.seed(7)
+    random.seed(7)
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    games = play_games(fast, {"C": 2, "num_searches": 12}, 768, c960=True, max_plies=700)
+    finished = [g for g in games if g["result"] is not None]
+    assert len(finished) >= 0.5 * len(games)
+    longest = max(len(g["actions"]) for g in games)
+    assert longest > 256, longest                                   # the ring wrapped for some game
+    for g in games:
+        n = len(g["actions"])
+        assert n == len(g["states"]) == len(g["colours"]) == len(g["rewards"]) and n >= 1
+        assert all(abs(sum(a.values()) - 1.0) < 1e-6 and len(a) >= 1 for a in g["actions"][::37])
+        assert all(c0 != c1 for c0, c1 in zip(g["colours"], g["colours"][1:]))       # colours alternate
+        if g["result"] == "1/2-1/2":
+            assert set(g["rewards"]) == {0}
+        elif g["result"] is not None:
+            assert set(g["rewards"]) == {1, -1} or n == 1
+    results = {r: sum(1 for g in finished if g["result"] == r) for r in ("1-0", "0-1", "1/2-1/2")}
+    assert sum(results.values()) == len(finished)
