@@ -1071,14 +1071,21 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
+#define NN_MAX_DEVICES 16
+static int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % NN_MAX_DEVICES;
+}
 static int device_cus() {
-    static int n_cu = 0;
-    if (!n_cu) {
+    static int n_cu[NN_MAX_DEVICES] = {};
+    int& n = n_cu[current_device_slot()];
+    if (!n) {
         int dev = 0; hipDeviceProp_t prop;
-        n_cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
     }
-    return n_cu;
+    return n;
 }
 static int default_flags(int flags, int wgb) {
     if (wgb == 2 && !(flags & (32 | 64 | 0xFF00)) && !(flags & 0x10000)) flags |= 32 | (3 << 8);   // stagger the first co-resident pair
@@ -1089,7 +1096,8 @@ template <int CIN, int NTAPS, int WGB> static int launch_conv(const void* in, co
     constexpr int PITCH = CIN * 2 + 16;
     const size_t lds_in = (size_t)(WGB * 64 + 1) * PITCH, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + 16);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_conv_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1103,7 +1111,8 @@ template <int CIN, int NTAPS, int WGB> static int launch_conv(const void* in, co
 
 template <int WGB> static int launch_block(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
     const size_t lds = (size_t)(WGB * 64 + 1) * (256 * 2 + 16);
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_block_bf16<WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1119,7 +1128,8 @@ template <int CIN, int NTAPS> static int launch_conv16(const void* in, const voi
     constexpr int WGB = 2, PITCH = CIN * 2 + NN_PAD16;
     const size_t lds_in = (size_t)(WGB * 64) * PITCH + NN_ZERO16, lds_out = (size_t)(WGB * 64) * (NN_COUT * 2 + NN_PAD16);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_conv16_bf16<CIN, NTAPS, WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1131,7 +1141,8 @@ template <int CIN, int NTAPS> static int launch_conv16(const void* in, const voi
 }
 template <int WGB> static int launch_block16(const void* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int n_boards, int flags, hipStream_t s) {
     const size_t lds = (size_t)(WGB * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16;
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_block16_bf16<WGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1212,7 +1223,8 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         prm.w[i] = (const uint4*)w_packed[i]; prm.b[i] = bias[i];
     }
     const size_t lds = 2 * ((size_t)(2 * 64) * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16) + 9 * 8 * 64 * sizeof(int);   // two images + tap address table
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1248,7 +1260,8 @@ int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float*
                           float* value, int32_t n_boards, void* stream) {
     if (!x || !wv || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
     const size_t lds = (64 * 256 + 16 * 64) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1265,7 +1278,8 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
                      int32_t n_boards, int32_t do_softmax, void* stream) {
     if (!x || !w_p1_packed || !b_p1 || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0) return SZ_ERR_INVALID;
     const size_t lds_h = (size_t)(2 * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16 + 64, lds_v = (64 * 256 + 16 * 64) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
+    bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
         HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
