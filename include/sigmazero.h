@@ -7,8 +7,9 @@
  *
  * Conventions: every function returns SZ_OK (0) or a negative SZ_ERR_*; the engine owns all of its
  * device memory; tensors handed in by pointer stay owned by the caller; all device work is enqueued
- * on the caller's stream (pass torch.cuda.current_stream().cuda_stream); one engine per GPU per
- * process; not thread-safe.
+ * on the caller's stream (pass torch.cuda.current_stream().cuda_stream), which must belong to the
+ * engine's device (sz_config.device); every call makes that device current for its duration and
+ * restores the caller's current device; one engine per GPU per process; not thread-safe.
  */
 #ifndef SIGMAZERO_H
 #define SIGMAZERO_H
@@ -87,6 +88,14 @@ int sz_upload_game(sz_engine* e, int32_t board, const void* ring, int32_t ply, v
 /* mark boards (in)active for the next searches; host array of n_boards bytes */
 int sz_set_active(sz_engine* e, const uint8_t* active, void* stream);
 
+/* Batch compaction for ragged self-play (games of one call end at different plies, sim.py:46): with enable != 0 the boards that will
+ * search next (active, game not over, no error) are numbered 0..n_live-1 in board order, and from then on board b reads its policy / value
+ * from ROW slot(b) of policy_dev / value_dev and writes its network input to ROW slot(b) of planes_dev — so the network runs on n_live
+ * rows instead of n_boards.  Call between searches, after sz_play / sz_new_games / sz_set_active changed the live set (synchronises the
+ * stream to return n_live).  enable == 0 restores the identity mapping (row = board), the default.  Results per board do not depend on
+ * the mapping.  Per-board outputs (sz_root_children, sz_fetch_ply, sz_play's uniforms) stay indexed by board. */
+int sz_compact(sz_engine* e, int32_t enable, int32_t* n_live_out, void* stream);
+
 /* First half of MCTS0.search (mcts.py:43-75): create the roots (visit_count = 1), test them for
  * termination, and write the network input of every root into planes_dev [n_boards,119,8,8]. */
 int sz_search_begin(sz_engine* e, void* planes_dev, void* stream);
@@ -139,6 +148,17 @@ int sz_debug_step_stamps(sz_engine* e, void* dev_buffer);
  * action p*64+v), leaf depth, node count, edge count, status per board (host pointers, may be NULL). */
 int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges,
                      int32_t* status, void* stream);
+/* test / inspection: the WHOLE tree of one board after a search, depth-first in child order (= a recursive walk over Node.children
+ * of mctsnode.py:7-18).  Row 0 is the root itself (depth -1, action -1); rows 1.. are its descendants: depth (0 = root child),
+ * action index (action_taken), visit_count, value_sum (f64), prior (f32).  Host arrays of max_nodes entries (may be NULL to count);
+ * *n_out = number of nodes in the tree. */
+int sz_debug_tree(sz_engine* e, int32_t board, int32_t max_nodes, int32_t* depth, int32_t* action, int32_t* visits, double* value_sum,
+                  float* prior, int32_t* n_out, void* stream);
+/* test: the DEVICE code of Node.select / Node.get_ucb (mctsnode.py:23-37) on caller-supplied children, one wavefront per case.
+ * Case c owns children offsets[c]..offsets[c+1] (<= SZ_MAX_MOVES each) of vc (visit_count), value_sum (f64), prior (f32); parent_visits[c],
+ * c_puct[c].  Writes every child's UCB value and the selected child per case.  All device pointers. */
+int sz_debug_select(const int32_t* offsets_dev, const int32_t* vc_dev, const double* value_sum_dev, const float* prior_dev,
+                    const int32_t* parent_visits_dev, const float* c_dev, float* ucb_out_dev, int32_t* argmax_out_dev, int32_t n_cases, void* stream);
 /* copy one board's current game position record (SZ_POS_BYTES) to the host */
 int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, void* stream);
 

@@ -38,6 +38,7 @@ EXPORTS = {
     "sz_new_games": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sz_upload_game": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "sz_set_active": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sz_compact": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "sz_search_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sz_search_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sz_get_stats": (C.c_int, [C.c_void_p, C.POINTER(sz_stats), C.c_void_p]),
@@ -46,6 +47,8 @@ EXPORTS = {
     "sz_fetch_ply": (C.c_int, [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]),
     "sz_debug_pending": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
     "sz_debug_position": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "sz_debug_tree": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.POINTER(C.c_int32), C.c_void_p]),
+    "sz_debug_select": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]),
     "sz_nn_conv_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -18,7 +18,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SZ_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define SZ_HD inline
@@ -55,7 +55,7 @@ struct alignas(16) SzPos {
 // meta layout
 #define SZM_EP_SHIFT 0        // 8 bits: ep square + 1 (0 = None); set after ANY double push like python-chess
 #define SZM_TURN_BIT 8        // 1 = white to move
-#define SZM_HALF_SHIFT 9      // 8 bits halfmove clock (saturates at 255)
+#define SZM_HALF_SHIFT 9      // 8 bits halfmove clock; saturates at 255, which loses nothing: every clock >= 150 is the same 75-move terminal state
 #define SZM_IRREV_BIT 17      // move that led here was irreversible (Board.is_irreversible)
 #define SZM_EPLEGAL_BIT 18    // Board.has_legal_en_passant()
 #define SZM_REPS_SHIFT 19     // 3 bits: earlier occurrences in the reversible window, saturating at 4

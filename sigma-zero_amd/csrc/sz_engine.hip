@@ -51,6 +51,7 @@ struct View {
     int B, S, n_cap, e_cap, p_cap, learning, chess960, planes_dtype;
     float c_puct, noise;
     unsigned long long* dbg;    // diagnostic (sz_debug_step_stamps): 8 u64 per board, s_memtime at the phase boundaries of k_search_step; NULL = off
+    const int* slot;            // optional (sz_compact): row of board b in the network batch (planes / policy / value); NULL = identity
     const float* root_gamma;    // optional (non-reference) true Dirichlet root noise: [B][SZ_MAX_MOVES] Gamma(alpha,1) draws; NULL = reference behaviour
     SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
     // per-ply training record
@@ -101,6 +102,25 @@ __device__ __forceinline__ float ucb_value(int vc, double wsum, float prior, flo
     float r = 1.0f / (float)(vc + 1);
     float u = ((r * sqrt_parent) * c) * prior;
     return q + u;
+}
+
+// Node.select (mctsnode.py:23-31): argmax of get_ucb over the n contiguous children, first maximum wins (torch.argmax).
+// Lanes = children; wave64 xor-butterfly with lowest-index tie-break.  ucb_out (optional, test hook) receives every child's value.
+__device__ __forceinline__ int wave_select_child(const EdgeStat* ch, int n, int parentN, float c_puct, float* ucb_out) {
+    const int lane = lane_id();
+    const float sq = (float)sqrt((double)parentN);                      // math.sqrt(self.visit_count) in double, then a float32 operand
+    float best = 0.f; int bi = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+        EdgeStat s = ch[c];
+        float u = ucb_value(s.N, s.W, s.P, sq, c_puct);
+        if (ucb_out) ucb_out[c] = u;
+        if (bi == 0x7fffffff || u > best) { best = u; bi = c; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ob = __shfl_xor(best, off); int oi = __shfl_xor(bi, off);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+    }
+    return uni(bi);
 }
 
 struct BoardPtrs {
@@ -321,8 +341,8 @@ __global__ __launch_bounds__(64) void k_new_games(View v, const int* scharnagl, 
     X.meta = sz_finish_meta(X, checkers, n_legal, ep_legal, 0);
     if (lane_id() == 0) {
         bp.ring[0] = X;
-        Ctl c; memset(&c, 0, sizeof c);
-        c.status = ST_ACTIVE;
+        Ctl c = *bp.ctl;                                  // the cumulative counters (n_expand, n_term, sum_depth, sum_k, max_edges) survive a refill
+        c.status = ST_ACTIVE; c.n_nodes = c.n_edges = c.sims_done = 0; c.pend_node = c.pend_depth = c.game_ply = c.err = 0; c.game_result = 0;
         *bp.ctl = c;
     }
 }
@@ -336,11 +356,34 @@ __global__ void k_set_active(View v, const uint8_t* active) {
     c->status = st;
 }
 
+// network-batch rows for the boards that will search (active, game not over, no error), in board order: one workgroup, chunked scan
+__global__ __launch_bounds__(1024) void k_compact(View v, int* slot, int* n_live) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x, per = (v.B + 1023) / 1024, lo = t * per, hi = min(v.B, lo + per);
+    int c = 0;
+    for (int b = lo; b < hi; b++) { const int st = v.ctl[b].status; c += ((st & ST_ACTIVE) && !(st & (ST_GAMEOVER | ST_ERROR))) ? 1 : 0; }
+    cnt[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                     // inclusive Hillis-Steele scan over the 1024 chunk counts
+        int add = t >= off ? cnt[t - off] : 0;
+        __syncthreads();
+        cnt[t] += add;
+        __syncthreads();
+    }
+    int base = cnt[t] - c;
+    for (int b = lo; b < hi; b++) {
+        const int st = v.ctl[b].status;
+        const bool live = (st & ST_ACTIVE) && !(st & (ST_GAMEOVER | ST_ERROR));
+        slot[b] = live ? base++ : -1;
+    }
+    if (t == 1023) *n_live = cnt[1023];
+}
+
 // finish an uploaded game record (status only; the ring was copied by the host)
 __global__ void k_after_upload(View v, int b, int ply) {
     Ctl* c = v.ctl + b;
-    Ctl z; memset(&z, 0, sizeof z);
-    z.status = ST_ACTIVE; z.game_ply = ply;
+    Ctl z = *c;                                           // cumulative counters kept, per-game fields reset
+    z.status = ST_ACTIVE; z.n_nodes = z.n_edges = z.sims_done = 0; z.pend_node = z.pend_depth = z.err = 0; z.game_result = 0; z.game_ply = ply;
     *c = z;
 }
 
@@ -388,7 +431,8 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
     for (int i = lane; i < SZ_MASK_WORDS; i += 64) bp.pmask[i] = mask[i];
     wave_load_history(bp, path, 0, root_ply, X, hist);
     __syncthreads();
-    wave_encode(hist, X, planes ? (char*)planes + (size_t)b * planes_board_bytes(v.planes_dtype) : nullptr, v.planes_dtype,
+    const int row = v.slot ? uni(v.slot[b]) : b;              // network batch row of this board (compacted batches: live boards first)
+    wave_encode(hist, X, (planes && row >= 0) ? (char*)planes + (size_t)row * planes_board_bytes(v.planes_dtype) : nullptr, v.planes_dtype,
                 v.rec_planes ? v.rec_planes + (size_t)b * SZ_NUM_PLANES * 8 : nullptr);
     if (lane == 0) {
         Ctl* c = bp.ctl;
@@ -411,6 +455,8 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
     if (!(status & ST_SEARCHING) || (status & (ST_DONE | ST_ERROR))) return;
     int n_nodes = uni(bp.ctl->n_nodes), n_edges = uni(bp.ctl->n_edges), sims = uni(bp.ctl->sims_done);
     const int root_ply = uni(bp.ctl->game_ply);
+    const int row = v.slot ? uni(v.slot[b]) : b;              // network batch row of this board
+    if (row < 0) return;
     unsigned long long n_expand = 0, n_term = 0, sum_depth = 0, sum_k = 0;
     int err = 0;
     STEP_STAMP(0);
@@ -421,7 +467,7 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
         for (int j = lane; j <= d; j += 64) path[j] = bp.gpath[j];
         for (int i = lane; i < SZ_MASK_WORDS; i += 64) mask[i] = bp.pmask[i];
         __syncthreads();
-        const float* pol = policy + (size_t)b * SZ_NUM_ACTIONS;
+        const float* pol = policy + (size_t)row * SZ_NUM_ACTIONS;
         // masked sum in the fixed order: per-lane partial over planes ascending, then xor butterfly.
         // Only planes that hold a legal move are fetched (~20 of 73), and in groups of 16 INDEPENDENT loads: a load-wait-add chain per
         // plane cost one full memory latency each, and fetching all 73 planes made the kernel bandwidth-bound at 4096 boards.  The
@@ -501,7 +547,7 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
         if (lane == 0) { bp.em[leaf_edge].first = first; bp.em[leaf_edge].n = (unsigned short)kept; }
         n_edges += kept;
         (void)node;
-        const double val = (double)value[b];                            // node.value = value.item()
+        const double val = (double)value[row];                          // node.value = value.item()
         wave_backprop(bp.es, path, d, val);
         sims++; n_expand++; sum_depth += d; sum_k += kept;
         status &= ~ST_PENDING;
@@ -516,18 +562,7 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
         int parentN = bp.es[0].N;
         m.first = uni(m.first); int mn = uni((int)m.n); parentN = uni(parentN);
         while (mn > 0) {                                                // Node.select
-            const float sq = (float)sqrt((double)parentN);
-            float best = 0.f; int bi = 0x7fffffff;
-            for (int c = lane; c < mn; c += 64) {
-                EdgeStat s = bp.es[m.first + c];
-                float u = ucb_value(s.N, s.W, s.P, sq, v.c_puct);
-                if (bi == 0x7fffffff || u > best) { best = u; bi = c; }
-            }
-            for (int off = 32; off >= 1; off >>= 1) {
-                float ob = __shfl_xor(best, off); int oi = __shfl_xor(bi, off);
-                if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
-            }
-            bi = uni(bi);
+            int bi = wave_select_child(bp.es + m.first, mn, parentN, v.c_puct, nullptr);
             cur = m.first + bi;
             d++;
             if (d >= v.p_cap) { err = SZ_ERR_CAPACITY; break; }
@@ -572,7 +607,7 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
         for (int j = lane; j <= d; j += 64) bp.gpath[j] = path[j];
         wave_load_history(bp, path, d, root_ply, X, hist);
         __syncthreads();
-        wave_encode(hist, X, (char*)planes + (size_t)b * planes_board_bytes(v.planes_dtype), v.planes_dtype, nullptr);
+        wave_encode(hist, X, (char*)planes + (size_t)row * planes_board_bytes(v.planes_dtype), v.planes_dtype, nullptr);
         status |= ST_PENDING;
         if (lane == 0) { bp.ctl->pend_node = nid; bp.ctl->pend_depth = d; }
         STEP_STAMP(4);
@@ -678,6 +713,21 @@ __global__ __launch_bounds__(64) void k_play(View v, const double* uniforms) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// test hook (sz_debug_select): the device's Node.select / get_ucb on caller-supplied children, one wave per case
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_debug_select(const int* offsets, const int* vc, const double* wsum, const float* prior,
+                                                     const int* parent_visits, const float* c_puct, float* ucb_out, int* argmax_out) {
+    extern __shared__ u64 lds64[];
+    EdgeStat* ch = (EdgeStat*)lds64;                       // the case's children staged as the SoA records the search reads
+    const int cs = blockIdx.x, lo = offsets[cs], n = offsets[cs + 1] - lo;
+    if (n <= 0 || n > SZ_MAX_CHILDREN) { if (lane_id() == 0) argmax_out[cs] = -1; return; }
+    for (int c = lane_id(); c < n; c += 64) { EdgeStat s; s.W = wsum[lo + c]; s.N = vc[lo + c]; s.P = prior[lo + c]; ch[c] = s; }
+    __syncthreads();
+    const int bi = wave_select_child(ch, n, parent_visits[cs], c_puct[cs], ucb_out + lo);
+    if (lane_id() == 0) argmax_out[cs] = bi;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------------------
 struct sz_engine {
@@ -686,9 +736,19 @@ struct sz_engine {
     size_t lds_bytes;
     std::vector<void*> allocs;
     int* d_scharnagl; uint8_t* d_active;
+    int* d_slot; int* d_nlive;
 };
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
+
+// every entry point runs with the engine's device current and restores the caller's afterwards (one engine per GPU per process;
+// a rank whose torch current device is not the engine's must not see it changed under its feet)
+struct DeviceGuard {
+    int prev = -1; bool changed = false;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess); }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+#define ENGINE_GUARD(e) DeviceGuard _guard((e)->cfg.device)
 
 template <typename T> static int dalloc(sz_engine* e, T** p, size_t count) {
     void* q = nullptr;
@@ -723,7 +783,8 @@ int sz_device_count(void) {
 int sz_create(const sz_config* cfg, sz_engine** out) {
     if (!cfg || !out || cfg->n_boards <= 0 || cfg->num_searches < 0) return SZ_ERR_INVALID;
     if (sz_device_count() <= 0) return SZ_ERR_NO_DEVICE;
-    HIPCHK(hipSetDevice(cfg->device));
+    if (cfg->device < 0 || cfg->device >= sz_device_count()) return SZ_ERR_INVALID;
+    DeviceGuard _guard(cfg->device);
     sz_engine* e = new sz_engine();
     e->cfg = *cfg;
     View& v = e->v;
@@ -758,7 +819,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
         (rc = dalloc(e, &v.rec_action, B * SZ_MAX_CHILDREN)) || (rc = dalloc(e, &v.rec_visits, B * SZ_MAX_CHILDREN)) ||
         (rc = dalloc(e, &v.rec_nchild, B)) || (rc = dalloc(e, &v.rec_colour, B)) || (rc = dalloc(e, &v.rec_chosen, B)) ||
         (rc = dalloc(e, &v.rec_over, B)) || (rc = dalloc(e, &v.rec_result, B)) || (rc = dalloc(e, &v.rec_active, B)) ||
-        (rc = dalloc(e, &e->d_scharnagl, B)) || (rc = dalloc(e, &e->d_active, B))) {
+        (rc = dalloc(e, &e->d_scharnagl, B)) || (rc = dalloc(e, &e->d_active, B)) || (rc = dalloc(e, &e->d_slot, B)) || (rc = dalloc(e, &e->d_nlive, 1))) {
         sz_destroy(e);
         return rc;
     }
@@ -772,6 +833,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
 
 int sz_destroy(sz_engine* e) {
     if (!e) return SZ_OK;
+    ENGINE_GUARD(e);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
     return SZ_OK;
@@ -779,6 +841,7 @@ int sz_destroy(sz_engine* e) {
 
 int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, void* stream) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     const size_t B = e->v.B;
     std::vector<int> sch(B, -1);
@@ -797,6 +860,21 @@ int sz_debug_step_stamps(sz_engine* e, void* dev_buffer) {
     return SZ_OK;
 }
 
+int sz_compact(sz_engine* e, int32_t enable, int32_t* n_live_out, void* stream) {
+    if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
+    if (!enable) { e->v.slot = nullptr; if (n_live_out) *n_live_out = e->v.B; return SZ_OK; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, e->v, e->d_slot, e->d_nlive);
+    HIPCHK(hipGetLastError());
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, e->d_nlive, sizeof n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    e->v.slot = e->d_slot;
+    if (n_live_out) *n_live_out = n;
+    return SZ_OK;
+}
+
 int sz_set_root_noise(sz_engine* e, const float* gamma_dev) {
     if (!e) return SZ_ERR_INVALID;
     e->v.root_gamma = gamma_dev;
@@ -805,6 +883,7 @@ int sz_set_root_noise(sz_engine* e, const float* gamma_dev) {
 
 int sz_set_active(sz_engine* e, const uint8_t* active, void* stream) {
     if (!e || !active) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(e->d_active, active, e->v.B, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -815,6 +894,7 @@ int sz_set_active(sz_engine* e, const uint8_t* active, void* stream) {
 
 int sz_upload_game(sz_engine* e, int32_t board, const void* ring, int32_t ply, void* stream) {
     if (!e || !ring || board < 0 || board >= e->v.B || ply < 0) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(e->v.ring + (size_t)board * SZ_RING, ring, SZ_RING * sizeof(SzPos), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -825,6 +905,7 @@ int sz_upload_game(sz_engine* e, int32_t board, const void* ring, int32_t ply, v
 
 int sz_search_begin(sz_engine* e, void* planes_dev, void* stream) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipLaunchKernelGGL(k_search_begin, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, planes_dev);
     HIPCHK(hipGetLastError());
     return SZ_OK;
@@ -832,6 +913,7 @@ int sz_search_begin(sz_engine* e, void* planes_dev, void* stream) {
 
 int sz_search_step(sz_engine* e, const float* policy_dev, const float* value_dev, void* planes_dev, void* stream) {
     if (!e || !policy_dev || !value_dev || !planes_dev) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipLaunchKernelGGL(k_search_step, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, policy_dev, value_dev, planes_dev);
     HIPCHK(hipGetLastError());
     return SZ_OK;
@@ -839,6 +921,7 @@ int sz_search_step(sz_engine* e, const float* policy_dev, const float* value_dev
 
 int sz_get_stats(sz_engine* e, sz_stats* out, void* stream) {
     if (!e || !out) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     std::vector<Ctl> h(e->v.B);
     HIPCHK(hipMemcpyAsync(h.data(), e->v.ctl, h.size() * sizeof(Ctl), hipMemcpyDeviceToHost, s));
@@ -857,6 +940,7 @@ int sz_get_stats(sz_engine* e, sz_stats* out, void* stream) {
 
 int sz_root_children(sz_engine* e, int32_t* action_dev, int32_t* visits_dev, int32_t* n_child_dev, float* prior_dev, double* value_sum_dev, void* stream) {
     if (!e || !action_dev || !visits_dev || !n_child_dev) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipLaunchKernelGGL(k_root_children, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, action_dev, visits_dev, n_child_dev, prior_dev, value_sum_dev);
     HIPCHK(hipGetLastError());
     return SZ_OK;
@@ -864,6 +948,7 @@ int sz_root_children(sz_engine* e, int32_t* action_dev, int32_t* visits_dev, int
 
 int sz_play(sz_engine* e, const double* uniforms_dev, void* stream) {
     if (!e || !uniforms_dev) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipLaunchKernelGGL(k_play, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, uniforms_dev);
     HIPCHK(hipGetLastError());
     return SZ_OK;
@@ -872,6 +957,7 @@ int sz_play(sz_engine* e, const double* uniforms_dev, void* stream) {
 int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t* visits, int32_t* n_child, uint8_t* colour, int32_t* chosen,
                  uint8_t* game_over, int8_t* result, uint8_t* active, void* stream) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     const size_t B = e->v.B;
     const View& v = e->v;
@@ -890,6 +976,7 @@ int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t*
 
 int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_nodes, int32_t* n_edges, int32_t* status, void* stream) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     const size_t B = e->v.B;
     std::vector<Ctl> h(B);
@@ -909,6 +996,7 @@ int sz_debug_pending(sz_engine* e, uint64_t* mask, int32_t* depth, int32_t* n_no
 
 int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, void* stream) {
     if (!e || board < 0 || board >= e->v.B || !pos_out) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     hipStream_t s = (hipStream_t)stream;
     Ctl c;
     HIPCHK(hipMemcpyAsync(&c, e->v.ctl + board, sizeof c, hipMemcpyDeviceToHost, s));
@@ -916,6 +1004,46 @@ int sz_debug_position(sz_engine* e, int32_t board, void* pos_out, int32_t* ply, 
     HIPCHK(hipMemcpyAsync(pos_out, e->v.ring + (size_t)board * SZ_RING + (c.game_ply & (SZ_RING - 1)), sizeof(SzPos), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ply) *ply = c.game_ply;
+    return SZ_OK;
+}
+
+int sz_debug_tree(sz_engine* e, int32_t board, int32_t max_nodes, int32_t* depth, int32_t* action, int32_t* visits, double* value_sum,
+                  float* prior, int32_t* n_out, void* stream) {
+    if (!e || board < 0 || board >= e->v.B || !n_out) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
+    hipStream_t s = (hipStream_t)stream;
+    Ctl c;
+    HIPCHK(hipMemcpyAsync(&c, e->v.ctl + board, sizeof c, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_out = 0;
+    if (!(c.status & ST_SEARCHING) || c.n_edges <= 0) return SZ_OK;
+    std::vector<EdgeStat> es(c.n_edges);
+    std::vector<EdgeMeta> em(c.n_edges);
+    HIPCHK(hipMemcpyAsync(es.data(), e->v.es + (size_t)board * e->v.e_cap, es.size() * sizeof(EdgeStat), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(em.data(), e->v.em + (size_t)board * e->v.e_cap, em.size() * sizeof(EdgeMeta), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // depth-first in child order = the order a recursive walk over Node.children visits the reference's tree; edge 0 is the root itself
+    std::vector<std::pair<int, int>> stack;                // (edge, depth)
+    int n = 0;
+    if (max_nodes > 0 && depth) { depth[0] = -1; action[0] = -1; visits[0] = es[0].N; value_sum[0] = es[0].W; prior[0] = es[0].P; }
+    n = 1;
+    for (int k = (int)em[0].n - 1; k >= 0 && em[0].first >= 0; k--) stack.push_back({em[0].first + k, 0});
+    while (!stack.empty()) {
+        auto [ed, d] = stack.back(); stack.pop_back();
+        if (n < max_nodes && depth) { depth[n] = d; action[n] = em[ed].action; visits[n] = es[ed].N; value_sum[n] = es[ed].W; prior[n] = es[ed].P; }
+        n++;
+        if (em[ed].first >= 0) for (int k = (int)em[ed].n - 1; k >= 0; k--) stack.push_back({em[ed].first + k, d + 1});
+    }
+    *n_out = n;
+    return SZ_OK;
+}
+
+int sz_debug_select(const int32_t* offsets_dev, const int32_t* vc_dev, const double* value_sum_dev, const float* prior_dev, const int32_t* parent_visits_dev,
+                    const float* c_dev, float* ucb_out_dev, int32_t* argmax_out_dev, int32_t n_cases, void* stream) {
+    if (!offsets_dev || !vc_dev || !value_sum_dev || !prior_dev || !parent_visits_dev || !c_dev || !ucb_out_dev || !argmax_out_dev || n_cases <= 0) return SZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_debug_select, dim3(n_cases), dim3(64), SZ_MAX_CHILDREN * sizeof(EdgeStat), (hipStream_t)stream, offsets_dev, vc_dev, value_sum_dev,
+                       prior_dev, parent_visits_dev, c_dev, ucb_out_dev, argmax_out_dev);
+    HIPCHK(hipGetLastError());
     return SZ_OK;
 }
 

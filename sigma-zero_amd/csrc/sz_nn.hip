@@ -1071,6 +1071,18 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
+// the network entry points carry no engine handle: they run on the device that owns the caller's stream (a rank whose current
+// device is another GPU would otherwise launch into the wrong context) and restore the caller's current device on return
+struct StreamDeviceGuard {
+    int prev = -1; bool changed = false;
+    explicit StreamDeviceGuard(void* stream) {
+        hipDevice_t sd = 0;
+        if (!stream || hipStreamGetDevice((hipStream_t)stream, &sd) != hipSuccess) return;     // the null stream belongs to the current device
+        if (hipGetDevice(&prev) == hipSuccess && prev != (int)sd) changed = (hipSetDevice((int)sd) == hipSuccess);
+    }
+    ~StreamDeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
 #define NN_MAX_DEVICES 16
 static int current_device_slot() {
     int dev = 0;
@@ -1161,6 +1173,7 @@ extern "C" {
 int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
                     int32_t n_boards, int32_t cin, int32_t ksize, int32_t relu, void* stream) {
     if (!in || !w_packed || !bias || !out || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     hipStream_t s = (hipStream_t)stream;
     if ((relu & SZ_NN_IN_BITS) && !((relu & SZ_NN_W16) && ksize == 3 && cin == 128)) return SZ_ERR_INVALID;
     if (relu & SZ_NN_W16) {                                // weights packed for the 16x16x32 path (sz_nn_pack_weights16)
@@ -1182,6 +1195,7 @@ int sz_nn_conv_bf16(const void* in, const void* w_packed, const float* bias, con
 int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2, void* out,
                      int32_t n_boards, int32_t flags, void* stream) {
     if (!in || !w1_packed || !bias1 || !w2_packed || !bias2 || !out || in == out || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     if (flags & SZ_NN_W16) return (flags & 0x80000) ? launch_block16<1>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream)   // A/B: 1-board workgroups, 3-4 per CU
                                                     : launch_block16<2>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
     return launch_block<2>(in, w1_packed, bias1, w2_packed, bias2, out, n_boards, flags, (hipStream_t)stream);
@@ -1216,6 +1230,7 @@ int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode) { g_tower_stamps = 
 // cin_padded 128; biases [256] f32 with BatchNorm folded), given as HOST arrays of device pointers.
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out, int32_t n_boards, int32_t flags, void* stream) {
     if (!planes || !w_packed || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     TowerParams prm;
     memset(&prm, 0, sizeof prm);
     for (int i = 0; i < 1 + 2 * n_blocks; i++) {
@@ -1250,6 +1265,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
 // w_packed from sz_nn_pack_head16 (73 output channels padded to 80), bias [73] f32.
 int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bias, float* probs, int32_t n_boards, int32_t do_softmax, void* stream) {
     if (!t || !w_packed || !bias || !probs || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     hipLaunchKernelGGL(k_policy_head, dim3((n_boards + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)t, (const uint4*)w_packed, bias, probs, n_boards, do_softmax);
     HIPCHK(hipGetLastError());
     return SZ_OK;
@@ -1259,6 +1275,7 @@ int sz_nn_policy_head_bf16(const void* t, const void* w_packed, const float* bia
 int sz_nn_value_head_bf16(const void* x, const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b,
                           float* value, int32_t n_boards, void* stream) {
     if (!x || !wv || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     const size_t lds = (64 * 256 + 16 * 64) * sizeof(float);
     static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
     bool& attr_set = attr_flags[current_device_slot()];
@@ -1277,6 +1294,7 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
                      const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch,
                      int32_t n_boards, int32_t do_softmax, void* stream) {
     if (!x || !w_p1_packed || !b_p1 || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
     const size_t lds_h = (size_t)(2 * 64) * (256 * 2 + NN_PAD16) + NN_ZERO16 + 64, lds_v = (64 * 256 + 16 * 64) * sizeof(float);
     static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
     bool& attr_set = attr_flags[current_device_slot()];

@@ -38,9 +38,14 @@ def _pack(w, cin_padded, ksize, device, w16=False):
 
 
 class FastPolicyNet:
-    def __init__(self, model, device="cuda:0", mfma16=True):
+    def __init__(self, model, device=None, mfma16=True):
         model = model.eval()
+        if device is None:                   # the GPU the fp32 module lives on, else this process's current device (never a silent cuda:0)
+            pdev = next(model.parameters()).device
+            device = pdev if pdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         dev = self.device
         self.w16 = bool(mfma16)              # 16x16x32 MFMA kernels (higher sustained clock) vs 32x32x16
         self.flag = N.SZ_NN_W16 if self.w16 else 0
@@ -88,7 +93,7 @@ class FastPolicyNet:
             bs = [self.stem[1]] + [b for blk in self.blocks for b in (blk[1], blk[3])]
             self._tower_w = (C.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
             self._tower_b = (C.c_void_p * len(bs))(*[t.data_ptr() for t in bs])
-        self._bufs = {}
+        self._bufs, self._full, self._cap = {}, None, 0
         self.fuse_blocks = True      # one launch per BasicBlock (sz_nn_block_bf16); False = two sz_nn_conv_bf16 launches
         self.timing = None          # optional list: (start, end) HIP event pairs around every 3x3 C_in=256 conv launch
 
@@ -99,8 +104,19 @@ class FastPolicyNet:
         return self
 
     def _buffers(self, B):
+        """activation / output buffers for a batch of B boards: views of ONE capacity-sized set that only ever grows (a self-play
+        run whose live-board count shrinks ply by ply must not leave a 400 MB allocation behind per distinct batch size)"""
+        if B > self._cap:
+            dev = self.device
+            self._full = [torch.empty(B, 64, 256, dtype=torch.bfloat16, device=dev) for _ in range(3)] + \
+                         [torch.empty(B, 4672, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+                          torch.empty(B, 64, dtype=torch.float32, device=dev)]
+            self._cap = B
+            self._bufs = {}
         if B not in self._bufs:
-            self._bufs[B] = [torch.empty(B, 64, 256, dtype=torch.bfloat16, device=self.device) for _ in range(3)]
+            if len(self._bufs) > 64:
+                self._bufs = {}
+            self._bufs[B] = [t[:B] for t in self._full]
         return self._bufs[B]
 
     def _conv(self, x, w, b, res, out, B, cin, ksize, relu=1):
@@ -164,11 +180,7 @@ class FastPolicyNet:
         B = planes.shape[0]
         x, scratch = self.tower(planes)
         if self.native_heads:
-            if B not in self._bufs or len(self._bufs[B]) < 6:
-                self._bufs[B] = self._bufs[B][:3] + [torch.empty(B, 4672, dtype=torch.float32, device=self.device),
-                                                     torch.empty(B, dtype=torch.float32, device=self.device),
-                                                     torch.empty(B, 64, dtype=torch.float32, device=self.device)]
-            policy, value, v1 = self._bufs[B][3], self._bufs[B][4], self._bufs[B][5]
+            policy, value, v1 = self._buffers(B)[3:6]
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             if self.fused_heads and self.w16:
                 P = lambda t: C.c_void_p(t.data_ptr())

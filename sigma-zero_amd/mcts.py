@@ -3,7 +3,8 @@ lives in HBM and every step of the search runs in the HIP engine (one wavefront 
 import torch
 
 from .chess_tensor import ChessTensor, Move
-from .selfplay import SelfPlayEngine, NOISE_REFERENCE
+from .mctsnode import Node
+from .selfplay import SelfPlayEngine, NOISE_REFERENCE, model_device
 
 device = "cuda" if torch.cuda.is_available() else "cpu"
 
@@ -14,9 +15,12 @@ class MCTS0:
     def __init__(self, game=None, args=None, model=None):
         self.game = game
         self.args = args
-        self.model = model.to(device)                         # mcts.py:36
+        # mcts.py:36 `model.to(device)`: a CPU model moves to this process's current GPU, a model already on cuda:N stays THERE
+        self.device = model_device(model) if torch.cuda.is_available() else torch.device("cpu")
+        self.model = model.to(self.device)
         self._engines = {}
-        self.last_root = None
+        self._tree = None
+        self._root = None
 
     def _engine(self, learning):
         key = (bool(learning), bool(self.game.chess960))
@@ -25,23 +29,44 @@ class MCTS0:
             if dtype not in (torch.float32, torch.bfloat16):
                 dtype = torch.float32
             self._engines[key] = SelfPlayEngine(self.model, self.args, 1, chess960=key[1], learning=key[0], planes_dtype=dtype,
-                                                noise_value=self.args.get("noise_value", NOISE_REFERENCE))
+                                                noise_value=self.args.get("noise_value", NOISE_REFERENCE), device=self.device)
         return self._engines[key]
 
     @torch.no_grad()
     def search(self, state=None, verbose=True, learning=False):
         """Returns {Move: visit_count / total} over the root's children in ascending action-index order (mcts.py:113-122).
-        `state` (the chess.Board of the reference signature) is implied by self.game, which search() uses un-copied (mcts.py:43)."""
+        `state` is the chess.Board of the reference signature: the reference reads only `state.turn` from it (root colour,
+        mcts.py:43) and searches self.game, un-copied; so does this — a `state` whose side to move contradicts self.game is refused."""
         if not isinstance(self.game, ChessTensor):
             raise TypeError("MCTS0.search needs the ChessTensor game object it was constructed with")
+        if state is not None and hasattr(state, "turn") and bool(state.turn) != bool(self.game.board.turn):
+            raise ValueError("state.turn contradicts the game MCTS0 was constructed with (mcts.py:43 takes the root colour from state.turn)")
         eng = self._engine(learning)
         eng.upload_game(0, self.game)
         eng.search()
         eng.check_errors()
         action, visits, n_child, prior, wsum = eng.root_children()
         k = int(n_child[0])
-        self.last_root = dict(action=action[0, :k].copy(), visits=visits[0, :k].copy(), prior=prior[0, :k].copy(), value_sum=wsum[0, :k].copy())
+        self._tree = eng.debug_tree(0)
+        self._root = None
         total = int(visits[0, :k].sum())
         if k and total == 0:
             raise ZeroDivisionError("division by zero")          # num_searches == 1, mcts.py:118-120
         return {self.game.move_from_index(int(a)): int(v) / total for a, v in zip(action[0, :k], visits[0, :k])}
+
+    @property
+    def root(self):
+        """The finished tree as reference-style Node objects (mctsnode.py:7-18 fields), built on first access from the engine's store."""
+        if self._root is None and self._tree is not None:
+            self._root = Node.from_engine_tree(self.game, self.args, self._tree)
+        return self._root
+
+    @property
+    def last_root(self):
+        """arrays of the root's children (ascending action index): action, visits, prior, value_sum"""
+        r = self.root
+        if r is None:
+            return None
+        import numpy as np
+        return dict(action=np.array([c.action_index for c in r.children], np.int32), visits=np.array([c.visit_count for c in r.children], np.int32),
+                    prior=np.array([c.prior for c in r.children], np.float32), value_sum=np.array([c.value_sum for c in r.children], np.float64))

@@ -15,12 +15,31 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def model_device(model, default=None):
+    """The CUDA device a network lives on (FastPolicyNet.device, or its first parameter's), else `default`, else the current device.
+    Engines are created THERE: a rank with local_rank > 0 must not silently search on GPU 0."""
+    dev = getattr(model, "device", None)
+    if dev is None and hasattr(model, "parameters"):
+        try:
+            dev = next(iter(model.parameters())).device
+        except (StopIteration, TypeError):
+            dev = None
+    if dev is not None and torch.device(dev).type == "cuda":
+        dev = torch.device(dev)
+        return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+    if default is not None:
+        return torch.device(default)
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 class SelfPlayEngine:
-    def __init__(self, model, args, n_boards, chess960=False, learning=True, device="cuda:0", planes_dtype=torch.float32,
+    def __init__(self, model, args, n_boards, chess960=False, learning=True, device=None, planes_dtype=torch.float32,
                  noise_value=NOISE_REFERENCE, edges_per_board=0):
         if not torch.cuda.is_available():
             raise RuntimeError("SelfPlayEngine needs an MI355X (HIP) device: the search has no CPU fallback")
-        self.device = torch.device(device)
+        self.device = torch.device(device) if device is not None else model_device(model)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.model = model
         self.args = dict(args)
         self.B = int(n_boards)
@@ -36,7 +55,6 @@ class SelfPlayEngine:
         cfg = N.sz_config(self.B, self.S, float(args["C"]), int(bool(learning)), float(noise_value), int(self.chess960),
                           int(edges_per_board), code, self.device.index or 0)
         self._e = C.c_void_p()
-        torch.cuda.set_device(self.device)
         N.check(N.lib().sz_create(C.byref(cfg), C.byref(self._e)), "sz_create")
         dev = self.device
         if self.bits:
@@ -52,6 +70,7 @@ class SelfPlayEngine:
         self.root_prior = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.float32, device=dev)
         self.root_wsum = torch.zeros(self.B, N.SZ_MAX_MOVES, dtype=torch.float64, device=dev)
         self.nn_seconds = 0.0
+        self.n_rows = self.B          # rows of the network batch in use (sz_compact: live boards only)
         # NON-REFERENCE option (default off): args["root_dirichlet_alpha"] = alpha switches from the reference's noise (the constant
         # 1-2^-24 at every expansion, mcts.py:91-98) to AlphaZero's Dirichlet(alpha) noise on the root's children only
         self.root_alpha = self.args.get("root_dirichlet_alpha")
@@ -86,6 +105,14 @@ class SelfPlayEngine:
         act = np.ascontiguousarray(active, dtype=np.uint8)
         N.check(N.lib().sz_set_active(self._e, act.ctypes.data_as(C.c_void_p), self._stream()), "sz_set_active")
 
+    def compact(self, enable=True):
+        """Number the boards that will search next 0..n_live-1 (sz_compact): the network then runs on planes[:n_live] only.
+        Call between searches after play() / new_games() / set_active() changed the live set.  Returns n_live."""
+        n = C.c_int32()
+        N.check(N.lib().sz_compact(self._e, int(bool(enable)), C.byref(n), self._stream()), "sz_compact")
+        self.n_rows = int(n.value) if enable else self.B
+        return self.n_rows
+
     def evaluate(self, planes):
         """model(x, inference=True) -> (policy probabilities [B,4672] f32, value [B] f32)"""
         policy, value = self.model(planes, inference=True)
@@ -110,8 +137,11 @@ class SelfPlayEngine:
         """All num_searches simulations for every active board (mcts.py:49-109)."""
         ev = evaluator or self.evaluate
         self.begin()
+        if self.n_rows <= 0:
+            return
+        planes = self.planes if self.n_rows == self.B else self.planes[:self.n_rows]
         for _ in range(self.S):
-            policy, value = ev(self.planes)
+            policy, value = ev(planes)
             self.step(policy, value)
 
     def stats(self):
@@ -154,6 +184,17 @@ class SelfPlayEngine:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         N.check(N.lib().sz_debug_pending(self._e, p(mask), p(depth), p(n_nodes), p(n_edges), p(status), self._stream()), "sz_debug_pending")
         return mask, depth, n_nodes, n_edges, status
+
+    def debug_tree(self, board):
+        """whole tree of one board, depth-first in child order: (depth, action, visits, value_sum, prior) arrays; row 0 = the root"""
+        n = C.c_int32()
+        N.check(N.lib().sz_debug_tree(self._e, int(board), 0, None, None, None, None, None, C.byref(n), self._stream()), "sz_debug_tree")
+        k = n.value
+        d, a, v = (np.zeros(k, np.int32) for _ in range(3))
+        w, pr = np.zeros(k, np.float64), np.zeros(k, np.float32)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(N.lib().sz_debug_tree(self._e, int(board), k, p(d), p(a), p(v), p(w), p(pr), C.byref(n), self._stream()), "sz_debug_tree")
+        return d, a, v, w, pr
 
     def debug_position(self, board):
         pos = np.zeros(10, np.uint64)

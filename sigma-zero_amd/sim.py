@@ -7,9 +7,9 @@ import numpy as np
 import torch
 
 from .chess_tensor import ChessTensor, Move, index_to_move, QUEEN
-from .selfplay import SelfPlayEngine, unpack_planes
+from .selfplay import SelfPlayEngine, unpack_planes, model_device
 
-device = "cuda" if torch.cuda.is_available() else "cpu"
+device = "cuda" if torch.cuda.is_available() else "cpu"      # module global of the reference (sim.py:12); the engine itself follows the model's device
 
 
 def _moves_for_record(action_idx, colour_white, packed_root):
@@ -28,12 +28,25 @@ def _moves_for_record(action_idx, colour_white, packed_root):
 
 
 def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, learning=True, planes_dtype=None, max_plies=100000,
-               verbose=False):
-    """Plays n_games concurrently.  Returns a list of per-game history dicts (sim.py:38-43 layout).
-    scharnagl: start index per game (default: python `random.randint(0,959)` per game like chess_tensor.py:69).
-    uniforms(game, ply) -> float: the np.random.random_sample() draw of sim.py:68 (default: global numpy RNG, drawn per ply in game order)."""
+               verbose=False, n_boards=None, compact=True, stats=None):
+    """Plays n_games games to the end and returns a list of per-game history dicts (sim.py:38-43 layout), game g at index g.
+
+    The games run concurrently on `n_boards` board slots of one engine (default: one slot per game).  A slot whose game ends is
+    REFILLED with the next game that has not started yet, so the GPU stays full until fewer than n_boards games remain; from then
+    on the batch is COMPACTED (sz_compact): the network only evaluates the boards that still play.  Per-game results do not depend
+    on the slot a game runs in or on what runs beside it.
+
+    scharnagl: start index per game (default: python `random.randint(0,959)` per game like chess_tensor.py:69, drawn in game order).
+    uniforms(game, ply) -> float: the np.random.random_sample() draw of sim.py:68.  Default: the global numpy RNG, drawn once per ply
+      for every running game in game order (n_games == 1 reproduces the reference's stream; for several concurrent games the order of
+      the draws necessarily differs from the reference's one-game-after-another order — generate_training_data(rng_order="reference")).
+    max_plies: a game still running after that many plies is cut (result None, rewards 0).
+    stats: optional dict, receives 'sims', 'nn_rows', 'plies' (work done; nn_rows = network rows evaluated)."""
     import random
-    model = model.to(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("self-play needs an MI355X (HIP) device: the search has no CPU fallback")
+    dev = model_device(model)                               # the model's own GPU (a rank with local_rank > 0 plays on ITS device)
+    model = model.to(dev)
     if planes_dtype is None:
         if hasattr(model, "tower"):                       # FastPolicyNet: hand-written MFMA tower, NHWC planes
             planes_dtype = "bits128" if getattr(model, "w16", False) else "nhwc128"     # bit-packed: 1 KiB per board instead of 16
@@ -45,54 +58,80 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
         scharnagl = [random.randint(0, 959) for _ in range(n_games)]
     if not c960:
         scharnagl = [-1] * n_games
-    eng = SelfPlayEngine(model, args, n_games, chess960=c960, learning=learning, planes_dtype=planes_dtype)
-    eng.new_games(scharnagl)
+    B = max(1, min(int(n_games), int(n_boards) if n_boards else int(n_games)))
+    S = int(args["num_searches"])
+    eng = SelfPlayEngine(model, args, B, chess960=c960, learning=learning, planes_dtype=planes_dtype, device=dev)
     games = [dict(states=[], actions=[], rewards=[], colours=[], result=None) for _ in range(n_games)]
-    alive = np.ones(n_games, dtype=bool)
-    ply = 0
+    slot_game = np.full(B, -1, dtype=np.int64)            # game running on each board slot, -1 = none
+    plies = np.zeros(n_games, dtype=np.int64)             # plies played so far per game
+    next_game = 0
+    work = dict(sims=0, nn_rows=0, plies=0)
 
-    def absorb(rec, was_alive):
+    def refill(slots):
+        """start the next waiting games on these slots (ChessTensor.__init__/start_board for each); the rest go dark"""
+        nonlocal next_game
+        sch, act = np.full(B, -1, dtype=np.int32), np.zeros(B, dtype=np.uint8)
+        for s_ in slots:
+            if next_game < n_games:
+                slot_game[s_] = next_game
+                sch[s_], act[s_] = scharnagl[next_game], 1
+                next_game += 1
+            else:
+                slot_game[s_] = -1
+        if act.any():
+            eng.new_games(sch, act)
+        eng.set_active((slot_game >= 0).astype(np.uint8))
+
+    def absorb(rec, game_of_slot):
         """host-side bookkeeping of one ply's records (sim.py:71-73); runs while the GPU searches the next ply"""
-        for g in np.nonzero(was_alive & rec["active"].astype(bool))[0]:
-            k = int(rec["n_child"][g])
-            white = bool(rec["colour"][g])
-            acts = rec["action"][g, :k]
-            vis = rec["visits"][g, :k].astype(np.int64)
+        for s_ in np.nonzero((game_of_slot >= 0) & rec["active"].astype(bool))[0]:
+            g = int(game_of_slot[s_])
+            k = int(rec["n_child"][s_])
+            white = bool(rec["colour"][s_])
+            acts = rec["action"][s_, :k]
+            vis = rec["visits"][s_, :k].astype(np.int64)
             total = int(vis.sum())
-            moves = _moves_for_record(acts, white, rec["packed"][g])
-            games[g]["states"].append(torch.from_numpy(unpack_planes(rec["packed"][g])))
+            moves = _moves_for_record(acts, white, rec["packed"][s_])
+            games[g]["states"].append(torch.from_numpy(unpack_planes(rec["packed"][s_])))
             games[g]["actions"].append({m: int(v) / total for m, v in zip(moves, vis)})
             games[g]["colours"].append(white)
-            if rec["game_over"][g]:
-                games[g]["result"] = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}[int(rec["result"][g])]
+            if rec["game_over"][s_]:
+                games[g]["result"] = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}[int(rec["result"][s_])]
 
+    refill(range(B))
     pending = None
-    while alive.any() and ply < max_plies:
+    while (slot_game >= 0).any():
+        n_rows = eng.compact() if compact else B
         eng.search()                                       # enqueues num_searches x (network + tree step); returns before the GPU is done
         if pending is not None:
             absorb(*pending)                               # previous ply's records, overlapped with this ply's search
             pending = None
         eng.check_errors()
-        u = np.zeros(n_games, dtype=np.float64)
-        for g in range(n_games):
-            if alive[g]:
-                u[g] = uniforms(g, ply) if uniforms is not None else np.random.random_sample()
+        u = np.zeros(B, dtype=np.float64)
+        running = np.nonzero(slot_game >= 0)[0]
+        for s_ in running[np.argsort(slot_game[running], kind="stable")]:      # draws in game order
+            g = int(slot_game[s_])
+            u[s_] = uniforms(g, int(plies[g])) if uniforms is not None else np.random.random_sample()
         eng.play(u)
         rec = eng.fetch_ply()
-        st = eng.stats()
-        if st["boards_error"]:
+        if eng.stats()["boards_error"]:
             eng.check_errors()
-        pending = (rec, alive.copy())
-        alive &= ~(rec["game_over"].astype(bool) & rec["active"].astype(bool))
-        ply += 1
+        pending = (rec, slot_game.copy())
+        work["sims"] += S * len(running); work["nn_rows"] += S * n_rows; work["plies"] += 1
+        plies[slot_game[running]] += 1
+        done = [int(s_) for s_ in running if (rec["game_over"][s_] and rec["active"][s_]) or plies[slot_game[s_]] >= max_plies]
+        if done:
+            refill(done)
         if verbose:
-            print("ply %d: %d games alive" % (ply, int(alive.sum())))
+            print("ply %d: %d games running, %d waiting, %d network rows" % (work["plies"], int((slot_game >= 0).sum()), n_games - next_game, n_rows))
     if pending is not None:
         absorb(*pending)
     for g in range(n_games):
         reward = {"1-0": 1, "0-1": -1}.get(games[g]["result"], 0)
         games[g]["rewards"] = [reward if i % 2 == 0 else -reward for i in range(len(games[g]["actions"]))]   # sim.py:94-97
     eng.close()
+    if stats is not None:
+        stats.update(work)
     return games
 
 
@@ -102,10 +141,21 @@ def play_game(model, args, c960=False):
     return {k: g[k] for k in ("states", "actions", "rewards", "colours")}
 
 
-def generate_training_data(model, num_games=1, args=None, return_dict=None, c960=False):
-    """sim.py:102-123: concatenated histories of num_games games; also stored under return_dict[os.getpid()]."""
+def generate_training_data(model, num_games=1, args=None, return_dict=None, c960=False, rng_order="batched", n_boards=None):
+    """sim.py:102-123: concatenated histories of num_games games; also stored under return_dict[os.getpid()].
+    rng_order="batched" (default): all games run concurrently; python's `random` (Chess960 starts) and numpy's global RNG (move
+      sampling) are consumed per ply across the running games, so the games differ from the ones the reference would draw from the
+      same seeds (same distribution).
+    rng_order="reference": one game after another, exactly the reference's order of RNG draws — same seeds, same games as
+      sim.py:114-118 (bit for bit with a deterministic network); one board on the GPU, for checks rather than for throughput."""
     games_history = {"states": [], "actions": [], "rewards": [], "colours": []}
-    for g in play_games(model, args, num_games, c960=c960):
+    if rng_order == "reference":
+        games = [play_games(model, args, 1, c960=c960)[0] for _ in range(num_games)]
+    elif rng_order == "batched":
+        games = play_games(model, args, num_games, c960=c960, n_boards=n_boards)
+    else:
+        raise ValueError("rng_order must be 'batched' or 'reference'")
+    for g in games:
         for key in games_history:
             games_history[key] += g[key]
     if return_dict is not None:

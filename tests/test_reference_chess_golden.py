@@ -1,0 +1,221 @@
+"""Pin the oracle (oracle/oc_tensor.c, oc_mcts.c) AND the product's host mirror to fixtures produced by running the reference's
+own chess_tensor.py / mcts.py / sim.py unmodified (tests/golden/gen_reference_chess_fixtures.py; rules supplied by the oracle's
+perft-pinned oc_chess.c through a `chess.Board` adapter — see tests/golden/_chess_stub/chess.py for what that does and does not pin).
+
+  chess_tensor_games.npz   26 games / 4,155 positions: get_representation(), both internal 119-plane stacks, terminal value,
+                           legal action indices (actionsToTensor) and their decode (tensorToAction) after EVERY ply
+  chess_search_traces.npz  MCTS0.search on real positions: every network input in order + the whole tree
+  chess_play_records.npz   sim.play_game / generate_training_data under seeded random / np.random
+"""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from hashmodel import evaluate_packed, pack_planes, unpack_planes
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _cases(z):
+    for i in range(int(z["n_cases"])):
+        yield i, {k[len("c%d_" % i):]: z[k] for k in z if k.startswith("c%d_" % i)}
+
+
+@pytest.fixture(scope="module")
+def games(golden_dir):
+    return _load(golden_dir, "chess_tensor_games.npz")
+
+
+def _oracle_stacks(ct):
+    """the two internal stacks of oc_ct (struct: board pointer, representation[119*64], black_representation[119*64])"""
+    raw = (C.c_uint8 * (2 * O.PLANES * 64)).from_address(ct._p + C.sizeof(C.c_void_p))
+    a = np.frombuffer(raw, dtype=np.uint8).reshape(2, O.PLANES, 8, 8)
+    return a[0], a[1]
+
+
+def _oracle_game(z, g, upto=None):
+    ct = O.ChessTensor(chess960=bool(z["c960"][g]), scharnagl=int(z["scharnagl"][g]) if z["c960"][g] else 518)
+    lo, hi = z["move_off"][g], z["move_off"][g + 1]
+    hi = hi if upto is None else lo + upto
+    for f, t, p in z["moves"][lo:hi]:
+        ct.move_piece(O.Move(int(f), int(t), int(p)))
+    return ct
+
+
+# ------------------------------------------------------------------------------------------------ A. ChessTensor
+def test_oracle_chess_tensor_matches_reference_every_ply(games):
+    z = games
+    n = 0
+    for g in range(int(z["n_games"])):
+        ct = O.ChessTensor(chess960=bool(z["c960"][g]), scharnagl=int(z["scharnagl"][g]) if z["c960"][g] else 518)
+        mlo = z["move_off"][g]
+        for k, s in enumerate(range(z["snap_off"][g], z["snap_off"][g + 1])):
+            tag = "game %d ply %d" % (g, k)
+            if k:
+                f, t, p = z["moves"][mlo + k - 1]
+                ct.move_piece(O.Move(int(f), int(t), int(p)))
+            assert np.array_equal(pack_planes(ct.get_representation()), z["rep"][s]), tag
+            w, b = _oracle_stacks(ct)
+            assert np.array_equal(pack_planes(w), z["white_stack"][s]) and np.array_equal(pack_planes(b), z["black_stack"][s]), tag
+            v, term = ct.get_value_and_terminated()
+            assert (v, int(term)) == (int(z["value"][s]), int(z["term"][s])), tag
+            assert ct.turn == int(z["turn"][s]), tag
+            idx, moves = ct.legal_action_indices()
+            lo, hi = z["idx_off"][s], z["idx_off"][s + 1]
+            assert idx == z["idx"][lo:hi].tolist(), tag
+            assert [m.key() for m in moves] == [tuple(int(x) for x in r) for r in z["back"][lo:hi]], tag
+            n += 1
+        res = {1: (1, 1), -1: (1, 0), 0: None, 2: None}[int(z["result"][g])]
+        o, winner = ct.board.outcome()
+        if res is not None:
+            assert (o, winner) == res
+    assert n == len(z["rep"]) >= 4000
+
+
+def test_illegal_move_raises_like_reference(games):
+    ct = O.ChessTensor()
+    with pytest.raises(ValueError):
+        ct.move_piece(O.Move.from_uci("e2e5"))
+
+
+def test_host_mirror_chess_tensor_matches_reference_every_ply(games):
+    """the product's ChessTensor (csrc/sz_chess.h through szh_*: the same rules + encoder code the kernels run) on the same games"""
+    import sigma_zero_amd as sz
+    z = games
+    for g in range(int(z["n_games"])):
+        ct = sz.ChessTensor(chess960=bool(z["c960"][g]), scharnagl=int(z["scharnagl"][g]) if z["c960"][g] else None)
+        mlo = z["move_off"][g]
+        for k, s in enumerate(range(z["snap_off"][g], z["snap_off"][g + 1])):
+            tag = "game %d ply %d" % (g, k)
+            if k:
+                f, t, p = z["moves"][mlo + k - 1]
+                ct.move_piece(sz.Move(int(f), int(t), int(p) or None))
+            assert np.array_equal(pack_planes(ct.get_representation().numpy()), z["rep"][s]), tag
+            assert ct.get_value_and_terminated() == (int(z["value"][s]), bool(z["term"][s])), tag
+            assert ct.board.turn == bool(z["turn"][s]), tag
+            lo, hi = z["idx_off"][s], z["idx_off"][s + 1]
+            assert ct.legal_action_indices() == z["idx"][lo:hi].tolist(), tag
+            assert [(m.from_square, m.to_square, m.promotion or 0) for m in ct.get_moves()] == [tuple(int(x) for x in r) for r in z["back"][lo:hi]], tag
+            if hi > lo:
+                mask, qp = sz.actionsToTensor(ct.get_valid_moves(), ct.board.turn)
+                assert mask.nonzero().flatten().tolist() == z["idx"][lo:hi].tolist(), tag
+                back = sz.tensorToAction(mask, ct.board.turn, qp)
+                assert [(m.from_square, m.to_square, m.promotion or 0) for m in back] == [tuple(int(x) for x in r) for r in z["back"][lo:hi]], tag
+        want = {1: "1-0", -1: "0-1", 0: "1/2-1/2", 2: "*"}[int(z["result"][g])]
+        assert ct.board.result() == want
+
+
+# ------------------------------------------------------------------------------------------------ B. search on real positions
+def _replay_search(z, case):
+    ct = _oracle_game(z, int(case["game"]), int(case["ply"]))
+    s = O.Search.on_chess(ct, c=2.0, num_searches=int(case["S"]), learning=bool(case["learning"]))
+    k = 0
+    while s.advance():
+        planes = pack_planes(s.leaf_planes())
+        assert k < len(case["leaf_planes"]) and np.array_equal(planes, case["leaf_planes"][k]), "network input %d differs" % k
+        pol, val = evaluate_packed(planes, str(case["mode"]), int(case["salt"]))
+        s.feed(pol, val)
+        k += 1
+    assert k == len(case["leaf_planes"])
+    return s
+
+
+def test_oracle_search_on_real_positions_matches_reference(games, golden_dir):
+    tr = _load(golden_dir, "chess_search_traces.npz")
+    n_exact = n_tol = 0
+    for i, case in _cases(tr):
+        tag = "case %d game %d ply %d S=%d learning=%d %s" % (i, case["game"], case["ply"], case["S"], case["learning"], case["mode"])
+        s = _replay_search(games, case)
+        d, a, v, w, p = s.dump_tree()
+        assert np.array_equal(d, case["tree_depth"]) and np.array_equal(a, case["tree_action"]), tag
+        assert np.array_equal(v, case["tree_visits"]), tag
+        assert s.root_visits() == int(case["root_visits"]), tag
+        if str(case["mode"]) == "dyadic":
+            assert np.array_equal(p.view(np.uint32), case["tree_prior"].view(np.uint32)), tag
+            assert np.array_equal(w, case["tree_value_sum"]) and s.root_value_sum() == float(case["root_value_sum"]), tag
+            n_exact += 1
+        else:
+            # torch.sum's reduction order vs the oracle's fixed order: <= 1 ulp on the normaliser (north star: 1e-4)
+            assert np.allclose(p, case["tree_prior"], rtol=3e-7, atol=0), tag
+            assert np.allclose(w, case["tree_value_sum"], rtol=0, atol=1e-12), tag
+            n_tol += 1
+        idx, vis, moves = s.root_children()
+        if str(case["error"]):
+            assert sum(vis) == 0, tag                      # mcts.py:118-120 divides by zero
+            continue
+        assert idx == case["root_actions"].tolist(), tag
+        assert [m.key() for m in moves] == [tuple(int(x) for x in r) for r in case["root_moves"]], tag
+        assert np.array_equal(np.array(vis, np.float64) / sum(vis), case["root_probs"]), tag
+    assert n_exact >= 30 and n_tol >= 8
+
+
+# ------------------------------------------------------------------------------------------------ C. play_game
+def _oracle_play_game(c960, scharnagl, S, mode, salt, uniform):
+    """sim.py:31-99 on the oracle: new search per ply, sample with the uniform np.random.choice would draw, move, rewards"""
+    ct = O.ChessTensor(chess960=c960, scharnagl=scharnagl if c960 else 518)
+    h = dict(states=[], actions=[], colours=[])
+    while not ct.get_value_and_terminated()[1]:
+        h["states"].append(pack_planes(ct.get_representation()))
+        s = O.Search.on_chess(ct, c=2.0, num_searches=S, learning=True)
+        while s.advance():
+            pol, val = evaluate_packed(pack_planes(s.leaf_planes()), mode, salt)
+            s.feed(pol, val)
+        idx, vis, moves = s.root_children()
+        tot = sum(vis)
+        h["actions"].append([(m.key(), v / tot) for m, v in zip(moves, vis)])
+        h["colours"].append(ct.turn)
+        ct.move_piece(moves[O.sample_move(vis, uniform())])
+    o, winner = ct.board.outcome()
+    reward = 0 if winner < 0 else (1 if winner == 1 else -1)
+    h["rewards"] = [reward if i % 2 == 0 else -reward for i in range(len(h["actions"]))]
+    return h
+
+
+def _check_history(h, case, lo=0):
+    n = len(h["actions"])
+    for k in range(n):
+        tag = "sample %d" % (lo + k)
+        assert np.array_equal(h["states"][k], case["states"][lo + k]), tag
+        a, b = case["act_off"][lo + k], case["act_off"][lo + k + 1]
+        assert [m for m, _ in h["actions"][k]] == [tuple(int(x) for x in r) for r in case["act_moves"][a:b]], tag
+        assert [p for _, p in h["actions"][k]] == case["act_probs"][a:b].tolist(), tag
+        assert int(h["colours"][k]) == int(case["colours"][lo + k]) and h["rewards"][k] == int(case["rewards"][lo + k]), tag
+    return n
+
+
+def test_oracle_play_game_matches_reference(golden_dir):
+    z = _load(golden_dir, "chess_play_records.npz")
+    n_games = 0
+    for i, case in _cases(z):
+        seed = int(case["seed"])
+        np.random.seed(seed)
+        sch = np.atleast_1d(case["scharnagl"]).tolist()
+        if str(case["kind"]) == "play_game":
+            h = _oracle_play_game(bool(case["c960"]), int(sch[0]), int(case["S"]), str(case["mode"]), int(case["salt"]), np.random.random_sample)
+            assert _check_history(h, case) == len(case["rewards"]), "case %d" % i
+            n_games += 1
+        else:
+            lo = 0
+            for g in range(int(case["num_games"])):
+                h = _oracle_play_game(bool(case["c960"]), int(sch[g]), int(case["S"]), str(case["mode"]), int(case["salt"]), np.random.random_sample)
+                lo += _check_history(h, case, lo)
+                n_games += 1
+            assert lo == len(case["rewards"])
+    assert n_games >= 9
+
+
+def test_scharnagl_draw_is_pythons_random(golden_dir):
+    """ChessTensor(chess960=True) draws random.randint(0, 959) (chess_tensor.py:69): the fixture's start index per seed"""
+    z = _load(golden_dir, "chess_play_records.npz")
+    for i, case in _cases(z):
+        if int(case["c960"]):
+            random.seed(int(case["seed"]))
+            want = np.atleast_1d(case["scharnagl"]).tolist()
+            assert [random.randint(0, 959) for _ in want] == want
