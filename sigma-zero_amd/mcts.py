@@ -21,6 +21,7 @@ class MCTS0:
         self._engines = {}
         self._tree = None
         self._root = None
+        self._root_game = None
 
     def _engine(self, learning):
         key = (bool(learning), bool(self.game.chess960))
@@ -48,6 +49,7 @@ class MCTS0:
         action, visits, n_child, prior, wsum = eng.root_children()
         k = int(n_child[0])
         self._tree = eng.debug_tree(0)
+        self._root_game = self.game.copy()                    # the view is built lazily; the caller may have moved self.game by then (sim.py:76)
         self._root = None
         total = int(visits[0, :k].sum())
         if k and total == 0:
@@ -58,7 +60,7 @@ class MCTS0:
     def root(self):
         """The finished tree as reference-style Node objects (mctsnode.py:7-18 fields), built on first access from the engine's store."""
         if self._root is None and self._tree is not None:
-            self._root = Node.from_engine_tree(self.game, self.args, self._tree)
+            self._root = Node.from_engine_tree(self._root_game, self.args, self._tree)
         return self._root
 
     @property

@@ -40,7 +40,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     uniforms(game, ply) -> float: the np.random.random_sample() draw of sim.py:68.  Default: the global numpy RNG, drawn once per ply
       for every running game in game order (n_games == 1 reproduces the reference's stream; for several concurrent games the order of
       the draws necessarily differs from the reference's one-game-after-another order — generate_training_data(rng_order="reference")).
-    max_plies: a game still running after that many plies is cut (result None, rewards 0).
+    max_plies: a game still running after that many plies is cut (result None, rewards 0); one number or one per game.
     stats: optional dict, receives 'sims', 'nn_rows', 'plies' (work done; nn_rows = network rows evaluated)."""
     import random
     if not torch.cuda.is_available():
@@ -58,6 +58,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
         scharnagl = [random.randint(0, 959) for _ in range(n_games)]
     if not c960:
         scharnagl = [-1] * n_games
+    cap = np.broadcast_to(np.asarray(max_plies, dtype=np.int64), (n_games,))
     B = max(1, min(int(n_games), int(n_boards) if n_boards else int(n_games)))
     S = int(args["num_searches"])
     eng = SelfPlayEngine(model, args, B, chess960=c960, learning=learning, planes_dtype=planes_dtype, device=dev)
@@ -119,7 +120,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
         pending = (rec, slot_game.copy())
         work["sims"] += S * len(running); work["nn_rows"] += S * n_rows; work["plies"] += 1
         plies[slot_game[running]] += 1
-        done = [int(s_) for s_ in running if (rec["game_over"][s_] and rec["active"][s_]) or plies[slot_game[s_]] >= max_plies]
+        done = [int(s_) for s_ in running if (rec["game_over"][s_] and rec["active"][s_]) or plies[slot_game[s_]] >= cap[slot_game[s_]]]
         if done:
             refill(done)
         if verbose:

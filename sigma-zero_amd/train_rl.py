@@ -106,11 +106,13 @@ class GradSync:
     so a few large buckets (default 4 x ~23 MB for the 91 MB fp32 gradient) keep the per-link pipeline full while the
     first buckets still overlap the tail of backward; tiny buckets would be launch/latency bound."""
 
-    def __init__(self, model, process_group=None, n_buckets=4):
+    def __init__(self, model, process_group=None, n_buckets=4, always_sync=False):
+        """always_sync: issue the collectives even in a 1-rank group (exercises the RCCL path on a single GPU; results unchanged)"""
         import torch.distributed as dist
         self.dist = dist
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (bool(always_sync) and dist.is_initialized())
         params = [p for p in model.parameters() if p.requires_grad]
         total = sum(p.numel() for p in params)
         self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
@@ -133,9 +135,20 @@ class GradSync:
                     self.bucket_params[b].append(p)
         self.handles = []
         self._left = None
-        if self.world > 1:
+        if self.collective:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._hook)
+
+    def common_batches(self, n_local):
+        """Number of batches EVERY rank can run in one pass: MIN over ranks of the local batch count.  Ranks hold different numbers
+        of samples (their games end at different plies), and every batch issues one all-reduce per bucket: a rank that ran more
+        batches than its peers would wait forever.  A rank with more samples than the minimum sees a different random subset of them
+        in each of the 7 passes (the batches are reshuffled per pass)."""
+        if not self.collective:
+            return int(n_local)
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=self.flat.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
 
     def begin_step(self):
         self.handles = []
@@ -152,10 +165,11 @@ class GradSync:
                     self.handles.append(self.dist.all_reduce(self.flat[blo:bhi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish_step(self):
-        if self.world > 1:
+        if self.collective:
             for h in self.handles:
                 h.wait()
-            self.flat.div_(self.world)
+            if self.world > 1:
+                self.flat.div_(self.world)
         self._left = None
 
     def zero(self):
@@ -173,11 +187,13 @@ def loss_fn(model, batch, device):
 
 def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0):
     """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce)."""
+    import itertools
     device = device or next(model.parameters()).device
     history = []
     model.train()
+    n_batches = sync.common_batches(len(dataloader)) if sync is not None else len(dataloader)     # identical on every rank
     for step in range(start_epoch, total_steps + 1):
-        for batch in dataloader:
+        for batch in itertools.islice(iter(dataloader), n_batches):
             if sync is not None:
                 sync.zero()
                 sync.begin_step()
@@ -198,11 +214,12 @@ def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=N
     return [(float(m), float(c)) for m, c in torch.stack(history).cpu().tolist()]
 
 
-def aggregate_throughput(counts, seconds, device="cpu"):
-    """Whole-job aggregation used by bench.py: SUM of per-rank unit counts, MAX of per-rank wall time (no-op on 1 rank)."""
+def aggregate_throughput(counts, seconds, device="cpu", force=False):
+    """Whole-job aggregation used by bench.py: SUM of per-rank unit counts, MAX of per-rank wall time (no-op on 1 rank unless
+    force=True, which runs the two all-reduces in a 1-rank group too)."""
     import torch.distributed as dist
     t = torch.tensor([float(c) for c in counts] + [float(seconds)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         mx = t.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -221,6 +238,21 @@ def save_cycle(model, optimiser, cycle, out_dir="saves"):
     os.makedirs(out_dir, exist_ok=True)
     torch.save(model.state_dict(), os.path.join(out_dir, "RL_%d.pt" % cycle))
     torch.save(optimiser.state_dict(), os.path.join(out_dir, "RL_opt_%d.pt" % cycle))
+
+
+def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
+    """Resume of train_RL.py:189-197 by intent: model weights from RL_{cycle}.pt AND optimiser state from RL_opt_{cycle}.pt (the
+    reference loads the model file into both, which cannot work).  Returns False — leaving model and optimiser untouched — when either
+    file is missing, like the reference's `except: start_epoch = 1`."""
+    mp, op = os.path.join(out_dir, "RL_%d.pt" % cycle), os.path.join(out_dir, "RL_opt_%d.pt" % cycle)
+    if not (os.path.exists(mp) and os.path.exists(op)):
+        return False
+    device = device or next(model.parameters()).device
+    msd = torch.load(mp, map_location=device, weights_only=True)
+    osd = torch.load(op, map_location=device, weights_only=True)
+    model.load_state_dict(msd)
+    optimiser.load_state_dict(osd)
+    return True
 
 
 def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True):
@@ -272,18 +304,21 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="RL loop of train_RL.py on the MI355X engine")
     ap.add_argument("--epochs", type=int, default=1)                  # train_RL.py:174 num_epochs (cycles)
     ap.add_argument("--start-epoch", type=int, default=1)             # :175
-    ap.add_argument("--games-per-rank", type=int, default=40)         # :165 num_games, per GPU here
+    ap.add_argument("--games-per-rank", default="40", help="train_RL.py:165 num_games, per GPU here; one number, or a comma list with one entry per rank")
     ap.add_argument("--searches", type=int, default=100)              # :170
     ap.add_argument("--batch-size", type=int, default=128)            # :173
     ap.add_argument("--total-steps", type=int, default=6)             # :261 -> 7 passes
     ap.add_argument("--chess960", type=int, default=1)                # :176
     ap.add_argument("--max-plies", type=int, default=100000)
     ap.add_argument("--init", default=None, help="state_dict to start from (reference checkpoints load: same keys)")
+    ap.add_argument("--init-opt", default=None, help="optimiser state_dict to start from (RL_opt_N.pt)")
     ap.add_argument("--save-dir", default="saves")
     ap.add_argument("--games-dir", default="games")
     ap.add_argument("--backend", default="nccl")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    gpr = [int(x) for x in str(a.games_per_rank).split(",")]
+    a.games_per_rank = gpr[rank] if len(gpr) > 1 else gpr[0]
     if not torch.cuda.is_available():
         raise SystemExit("train_rl needs an MI355X: self-play has no CPU path")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -295,22 +330,35 @@ def main(argv=None):
     model = policyNN({}).to(device)
     if a.init:
         model.load_state_dict(torch.load(a.init, map_location=device, weights_only=True))
+    optimiser = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)            # train_RL.py:187
+    start_epoch = a.start_epoch
+    if start_epoch > 1 and not a.init:                                                   # train_RL.py:189-197
+        if load_cycle(model, optimiser, start_epoch - 1, a.save_dir, device):
+            print("rank %d: resumed model + optimiser from cycle %d" % (rank, start_epoch - 1), flush=True)
+        else:
+            print("No saved weights from epoch %d found!" % (start_epoch - 1), flush=True)
+            start_epoch = 1
+    if a.init_opt:
+        optimiser.load_state_dict(torch.load(a.init_opt, map_location=device, weights_only=True))
+    sched = torch.optim.lr_scheduler.StepLR(optimiser, step_size=500, gamma=0.95)           # created after the resume, like train_RL.py:199
     sync_module_state(model, average_buffers=False)
-    optimiser, sched = make_optimiser(model)
     sync = GradSync(model) if world > 1 else None
     args = {"C": 2, "num_searches": a.searches, "max_plies": a.max_plies}
     import random
     random.seed(1000 + rank)
     np.random.seed(1000 + rank)
-    for epoch in range(a.start_epoch, a.start_epoch + a.epochs):
+    for epoch in range(start_epoch, start_epoch + a.epochs):
         hist, games = run_cycle(model, optimiser, sched, args, a.games_per_rank, chess960=bool(a.chess960), sync=sync,
                                 batch_size=a.batch_size, total_steps=a.total_steps)
         sync_module_state(model, average_buffers=True) if world > 1 else None
         n_samples = sum(len(g["actions"]) for g in games)
+        # games/RL_960_{epoch}.pt (train_RL.py:229-241 merges every worker's games into one file): rank 0 writes its games under the
+        # reference's name, every other rank writes games/RL_960_{epoch}.rank{r}.pt next to it (same layout; a merge is a key-wise
+        # concatenation — not done here: at 8 x 4096 games per cycle the merged pickle would be several GB through one process)
+        os.makedirs(a.games_dir, exist_ok=True)
+        torch.save(pack_games_for_save(games), os.path.join(a.games_dir, ("RL_960_%d.pt" % epoch) if rank == 0 else ("RL_960_%d.rank%d.pt" % (epoch, rank))))
         if rank == 0:
             save_cycle(model, optimiser, epoch, a.save_dir)
-            os.makedirs(a.games_dir, exist_ok=True)
-            torch.save(pack_games_for_save(games), os.path.join(a.games_dir, "RL_960_%d.pt" % epoch))
             last = hist[-1] if hist else (float("nan"), float("nan"))
             print("epoch %d: %d ranks x %d games, %d samples on rank 0, %d optimiser steps, last mse %.4f ce %.4f"
                   % (epoch, world, a.games_per_rank, n_samples, len(hist), last[0], last[1]), flush=True)

@@ -272,7 +272,14 @@ def test_generate_training_data_api():
             assert bool(st[112, 0, 0]) == col                       # colour plane of the mover's view
         assert g["colours"][0] is True and all(a != b for a, b in zip(g["colours"], g["colours"][1:]))
         assert set(g["rewards"]) <= {0, 1, -1}
-    data = sz.generate_training_data(net, num_games=3, args=args, return_dict={}, c960=False) if False else None
+    import os
+    rd = {}
+    data = sz.generate_training_data(net, num_games=3, args={"C": 2, "num_searches": 6, }, return_dict=rd, c960=False, n_boards=2)   # 3 games on 2 slots: refill
+    assert list(rd.keys()) == [os.getpid()] and rd[os.getpid()] is data                  # sim.py:120-121
+    assert set(data.keys()) == {"states", "actions", "rewards", "colours"}
+    n = len(data["actions"])
+    assert n > 0 and len(data["states"]) == len(data["rewards"]) == len(data["colours"]) == n
+    assert sum(1 for st in data["states"] if not st[113].any()) == 3                      # exactly num_games games: 3 start positions (plane 113 = any move played)
     # FastPolicyNet path through the same API
     from sigma_zero_amd.fastnet import FastPolicyNet
     games2 = sz.sim.play_games(FastPolicyNet(net), args, 4, c960=False, max_plies=4)
@@ -432,11 +439,14 @@ def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(root, "tools", "run_train_rl.py"), "--epochs", "1", "--games-per-rank", "6", "--searches", "4", "--batch-size", "8", "--total-steps", "0",
+           os.path.join(root, "tools", "run_train_rl.py"), "--epochs", "1", "--games-per-rank", "6,9", "--searches", "4", "--batch-size", "8", "--total-steps", "0",
            "--max-plies", "10", "--backend", "gloo", "--save-dir", str(tmp_path / "saves"), "--games-dir", str(tmp_path / "games")]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "epoch 1: 2 ranks x 6 games" in out.stdout
+    # rank 0 holds 60 samples = 7 batches of 8, rank 1 holds 90 = 11: both run MIN = 7 all-reduced steps (no deadlock)
+    assert "epoch 1: 2 ranks x 6 games" in out.stdout and "7 optimiser steps" in out.stdout
+    other = torch.load(tmp_path / "games" / "RL_960_1.rank1.pt", weights_only=True)
+    assert len(other["states"]) == 90
     sd = torch.load(tmp_path / "saves" / "RL_1.pt", weights_only=True)
     assert list(sd.keys()) == list(sz.policyNN({}).state_dict().keys())
     games = torch.load(tmp_path / "games" / "RL_960_1.pt", weights_only=True)

@@ -1,0 +1,162 @@
+"""GPU tests of (1) the RCCL code path of the optimiser step (backend "nccl" = RCCL, one rank: the collectives execute on the device),
+(2) how far the shipped bf16 MFMA network moves a SEARCH away from the fp32 network the reference uses (network.py has no mixed
+precision): same positions, same seeds, root visit distributions compared at S = 100 and S = 800, (3) ragged self-play through the
+product API: slot refill + batch compaction give bit-identical per-game records."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import sigma_zero_amd as sz
+from sigma_zero_amd import train_rl
+from sigma_zero_amd.fastnet import FastPolicyNet
+from sigma_zero_amd.selfplay import SelfPlayEngine
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ 1. RCCL
+def test_rccl_gradsync_and_aggregation_execute_on_the_device():
+    """north star: 'RCCL all-reduce over xGMI only for gradient sync in the optimiser step' (the loop of train_RL.py:219-264).
+    One rank, backend nccl: GradSync's bucketed all-reduces and bench.py's aggregation run through RCCL on device tensors."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        torch.manual_seed(0)
+        net = sz.policyNN({}).to(dev)
+        net.eval()
+        g = torch.Generator().manual_seed(5)
+        batch = {"states": (torch.rand(4, 119, 8, 8, generator=g) < 0.15).float(), "actions": torch.softmax(torch.randn(4, 4672, generator=g) * 3, 1),
+                 "rewards": torch.tensor([1., -1., 0., 1.])}
+        loss, _, _ = train_rl.loss_fn(net, batch, dev)
+        loss.backward()
+        ref = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+        net.zero_grad(set_to_none=True)
+        sync = train_rl.GradSync(net, n_buckets=4, always_sync=True)
+        assert sync.collective and sync.flat.is_cuda and sync.flat.numel() == 22_809_420
+        sync.zero(); sync.begin_step()
+        loss, _, _ = train_rl.loss_fn(net, batch, dev)
+        loss.backward()
+        assert len(sync.handles) == 4                                 # one asynchronous RCCL all-reduce per bucket, launched from backward hooks
+        sync.finish_step()
+        # SUM over one rank / 1 = the local gradient (torch's own conv backward is not run-to-run bitwise on the GPU, hence allclose here;
+        # the collective itself is checked exactly below)
+        assert torch.allclose(sync.flat, ref, rtol=1e-3, atol=1e-6)
+        t = torch.randn(1 << 20, device=dev)
+        t2 = t.clone()
+        dist.all_reduce(t2, op=dist.ReduceOp.SUM)
+        assert torch.equal(t, t2)
+        assert sync.common_batches(7) == 7                            # all_reduce(MIN) on the device
+        (a, b), t = train_rl.aggregate_throughput([123.0, 45.0], 2.5, device=dev, force=True)
+        assert (a, b, t) == (123.0, 45.0, 2.5)
+        opt, sched = train_rl.make_optimiser(net)
+        dl = train_rl.DeviceBatches([np.zeros((119, 8), np.uint8)] * 8, [np.array([1, 2])] * 8, [np.array([0.5, 0.5])] * 8, [1] * 8, batch_size=4, device=dev)
+        hist = train_rl.train(net, dl, opt, total_steps=0, lr_scheduler=sched, sync=sync, device=dev)
+        assert len(hist) == 2 and np.isfinite(hist).all()
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ 2. bf16 network vs fp32 network, at search level
+def _positions(n, seed):
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        ct = sz.ChessTensor(chess960=True, scharnagl=rng.randrange(960))
+        for _ in range(rng.randrange(0, 60)):
+            if ct.board.is_game_over():
+                break
+            idx = ct.legal_action_indices()
+            ct.push_action(idx[rng.randrange(len(idx))])
+        if not ct.board.is_game_over():
+            out.append(ct)
+    return out
+
+
+def _root_distributions(model, positions, S, planes_dtype):
+    eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, len(positions), chess960=True, learning=True, planes_dtype=planes_dtype)
+    for b, ct in enumerate(positions):
+        eng.upload_game(b, ct)
+    eng.search()
+    eng.check_errors()
+    action, visits, n_child, _, _ = eng.root_children()
+    eng.close()
+    return action, visits, n_child
+
+
+@pytest.mark.parametrize("S", [100, 800])
+def test_bf16_network_search_divergence_from_fp32(S):
+    """The shipped inference path (FastPolicyNet: bf16 MFMA tower) against the reference-precision network (fp32 policyNN) on the SAME
+    64 positions: legal-move sets and child order are identical by construction; what moves is the visit distribution.  The figures are
+    printed (and quoted in DESIGN.md §4); the bounds below are what the random-init network gives with margin."""
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    fast = FastPolicyNet(net)
+    pos = _positions(64, seed=S)
+    a32, v32, n32 = _root_distributions(net, pos, S, torch.float32)
+    a16, v16, n16 = _root_distributions(fast, pos, S, "bits128")
+    assert np.array_equal(n32, n16)
+    top_same, l1, linf, kl, top_share = [], [], [], [], []
+    for b in range(len(pos)):
+        k = int(n32[b])
+        assert np.array_equal(a32[b, :k], a16[b, :k])                          # same children, same order: indices are exact
+        p, q = v32[b, :k] / v32[b, :k].sum(), v16[b, :k] / v16[b, :k].sum()
+        top_same.append(int(np.argmax(p) == np.argmax(q)))
+        l1.append(float(np.abs(p - q).sum())); linf.append(float(np.abs(p - q).max()))
+        eps = 1e-9
+        kl.append(float(np.sum(p * np.log((p + eps) / (q + eps)))))
+        top_share.append(float(q[np.argmax(p)] / max(p.max(), eps)))           # how much of fp32's favourite's visits bf16 gives that move
+    rep = dict(S=S, boards=len(pos), top_move_agreement=float(np.mean(top_same)), mean_L1=float(np.mean(l1)), max_Linf=float(np.max(linf)),
+               mean_Linf=float(np.mean(linf)), mean_KL=float(np.mean(kl)), max_KL=float(np.max(kl)), favourite_share=float(np.mean(top_share)))
+    print("bf16-vs-fp32 search divergence:", json.dumps(rep))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bf16_vs_fp32_search_S%d.json" % S), "w") as f:
+        json.dump(rep, f)
+    # not within the north star's 1e-4 (that tolerance is met by the fp32 path: tests/test_gpu_parity.py, test_gpu_reference_golden.py);
+    # bounded so that a regression of the bf16 kernels shows up here
+    # measured on MI355X (round 2): S=100 mean L1 6.3e-4, max Linf 1.0e-2 (= one visit of 99), KL 1.1e-4; S=800 mean L1 1.2e-4, max Linf
+    # 1.3e-3 (= one visit of 799), KL 2.1e-6; the most-visited move agreed on 64/64 boards at both budgets
+    assert rep["mean_L1"] < 0.01 and rep["mean_KL"] < 1e-3 and rep["top_move_agreement"] >= 0.95 and rep["max_Linf"] <= 3.0 / (S - 1) + 1e-9, rep
+
+
+# ------------------------------------------------------------------------------------------------ 3. ragged self-play: refill + compaction
+def test_refill_and_compaction_give_identical_per_game_records():
+    """sim.py:102-123 plays exactly num_games games.  The product runs them on fewer board slots than games (slot refill) and evaluates
+    only the boards that still play (compaction); per-game records must be bit-identical to the plain run (one slot per game, no
+    compaction), because a game's results do not depend on what runs beside it."""
+    torch.manual_seed(0)
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    args = {"C": 2, "num_searches": 10}
+    n_games = 12
+    sch = [3 * g + 5 for g in range(n_games)]
+    caps = [6, 9, 14, 40, 11, 40, 7, 40, 25, 40, 40, 13]                     # ragged: games are cut at different plies (stand-in for different game lengths)
+
+    def uni(g, ply):
+        return ((g * 7919 + ply * 104729) % 1000003) / 1000003.0
+
+    def run(**kw):
+        st = {}
+        random.seed(1); np.random.seed(1)
+        games = sz.sim.play_games(fast, args, n_games, c960=True, scharnagl=sch, uniforms=uni, max_plies=caps, stats=st, **kw)
+        return games, st
+
+    plain, st_plain = run(compact=False)
+    packed, st_packed = run(n_boards=5, compact=True)
+    assert len(plain) == len(packed) == n_games
+    for g in range(n_games):
+        a, b = plain[g], packed[g]
+        assert len(a["actions"]) == len(b["actions"]) == caps[g], "game %d length" % g
+        assert a["rewards"] == b["rewards"] and a["colours"] == b["colours"] and a["result"] == b["result"]
+        for x, y in zip(a["states"], b["states"]):
+            assert torch.equal(x, y)
+        for x, y in zip(a["actions"], b["actions"]):
+            assert list(x.keys()) == list(y.keys()) and list(x.values()) == list(y.values())
+    assert st_plain["sims"] == st_packed["sims"]                       # the same work was done ...
+    assert st_packed["nn_rows"] <= st_packed["sims"] + 10 * 2 * st_packed["plies"]      # ... on network batches that held (almost) only live boards
+    assert st_plain["nn_rows"] == 12 * 10 * st_plain["plies"]

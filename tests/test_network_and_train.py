@@ -137,3 +137,84 @@ def test_bench_aggregation_two_ranks():
     mp.spawn(_agg_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
     assert out[0] == out[1] == ([300.0, 270.0], 2.0)
     assert train_rl.aggregate_throughput([5, 4], 0.5) == ([5.0, 4.0], 0.5)
+
+
+class _TinyNet(torch.nn.Module):
+    """policyNN's (policy logits, value) surface with a handful of parameters: the multi-rank training loop is the subject, not the net"""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Linear(119 * 64, 4672)
+        self.v = torch.nn.Linear(119 * 64, 1)
+
+    def forward(self, x, inference=False):
+        x = x.flatten(1)
+        return self.p(x), torch.tanh(self.v(x))
+
+
+def _fake_records(n, seed):
+    rng = np.random.RandomState(seed)
+    packed = [rng.randint(0, 256, size=(119, 8)).astype(np.uint8) for _ in range(n)]
+    aidx = [np.sort(rng.choice(4672, size=rng.randint(1, 30), replace=False)) for _ in range(n)]
+    aprob = [rng.dirichlet(np.ones(len(a))) for a in aidx]
+    rew = rng.choice([-1, 0, 1], size=n).tolist()
+    return packed, aidx, aprob, rew
+
+
+def _uneven_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    net = _TinyNet()
+    train_rl.sync_module_state(net, average_buffers=False)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sync = train_rl.GradSync(net, n_buckets=3)
+    # rank 0 holds 3 batches of 8, rank 1 holds 5 (+ a remainder): game lengths differ per rank in real self-play
+    n = [3 * 8 + 2, 5 * 8 + 5][rank]
+    dl = train_rl.DeviceBatches(*_fake_records(n, 10 + rank), batch_size=8, device="cpu", shuffle=True, generator=torch.Generator().manual_seed(rank))
+    hist = train_rl.train(net, dl, opt, total_steps=2, sync=sync, device=torch.device("cpu"))
+    out[rank] = (len(dl), len(hist), torch.cat([p.detach().flatten() for p in net.parameters()]).numpy())
+    # a rank without a single full batch must not hang its peers either: MIN is 0, nobody steps
+    dl0 = train_rl.DeviceBatches(*_fake_records([3, 40][rank], 20 + rank), batch_size=8, device="cpu")
+    out[10 + rank] = len(train_rl.train(net, dl0, opt, total_steps=1, sync=sync, device=torch.device("cpu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_training_with_unequal_batch_counts_does_not_deadlock():
+    """train_RL.py:219-264 on N ranks: every rank trains on its own games, so per-rank batch counts differ; every rank must run the
+    same number of all-reduced steps (MIN over ranks) and end with identical parameters"""
+    world = 2
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, 33500 + (os.getpid() % 2000), out), nprocs=world, join=True)
+    assert out[0][0] == 3 and out[1][0] == 5                      # local batch counts differ ...
+    assert out[0][1] == out[1][1] == 3 * 3                        # ... both ranks ran MIN(3,5) batches in each of the 3 passes
+    assert np.array_equal(out[0][2], out[1][2])                   # and hold the same parameters (same averaged gradients every step)
+    assert out[10] == out[11] == 0
+
+
+def test_optimiser_state_resume(tmp_path):
+    """train_RL.py:189-197 by intent: RL_{n}.pt -> model, RL_opt_{n}.pt -> optimiser; a missing pair leaves both untouched"""
+    torch.manual_seed(1)
+    net = _TinyNet()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-4)
+    dl = train_rl.DeviceBatches(*_fake_records(16, 3), batch_size=8, device="cpu", shuffle=False)
+    train_rl.train(net, dl, opt, total_steps=0)
+    train_rl.save_cycle(net, opt, 4, str(tmp_path))
+    net2 = _TinyNet()
+    opt2 = torch.optim.Adam(net2.parameters(), lr=1e-4, weight_decay=1e-4)
+    assert not train_rl.load_cycle(net2, opt2, 3, str(tmp_path))
+    assert train_rl.load_cycle(net2, opt2, 4, str(tmp_path))
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a, b)
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert s1.keys() == s2.keys() and len(s1) > 0
+    for k in s1:
+        assert torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) and torch.equal(s1[k]["exp_avg_sq"], s2[k]["exp_avg_sq"]) and s1[k]["step"] == s2[k]["step"]
+    # one more identical step on both: identical parameters afterwards (the Adam moments were really restored)
+    train_rl.train(net, dl, opt, total_steps=0)
+    train_rl.train(net2, dl, opt2, total_steps=0)
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a, b)
