@@ -18,8 +18,9 @@ One JSON line is printed by rank 0.  Extra objects:
                 rocprofv3 --pmc passes (profiles/pmc_tower_latest.json)
   roofline_tree the hand-written tree kernel (k_search_step), HBM roofline: algorithmic bytes per launch / mean launch duration
   roofline_nn   the whole network forward (tower + heads): 2.915 GFLOP x boards / mean forward duration
+  parity_config simulations/s of the same boards-per-GPU with the fp32 network the reference uses (bounded sample, N=1 only)
   cpu_baseline  the oracle (reference algorithm restated on the CPU: one leaf per step, per-game pointer tree,
-                batch-1 fp32 forward on the host cores), timed on rank 0 over a bounded sample
+                batch-1 fp32 forward on the host cores) on BASELINE.json configs[0], timed on rank 0 over a bounded sample
 """
 import argparse
 import json
@@ -59,8 +60,11 @@ def tree_bytes_per_launch(boards, sims, expansions, sum_depth, sum_children, pla
     return per_sim * sims + per_exp * expansions
 
 
-def cpu_baseline(num_searches, budget_s=15.0):
-    """Reference algorithm on the host cores: oracle search (per-game tree, one leaf per step) + batch-1 fp32 forward."""
+def cpu_baseline(budget_s=15.0):
+    """BASELINE.json configs[0] — the reference's own CPU-runnable case (sim.py:125-137): 1 self-play game, num_searches=10, Chess960
+    start, random-init network — played by the oracle (the reference algorithm restated on the CPU: per-game pointer tree, one leaf per
+    step, state copy + replay per leaf) with the batch-1 fp32 policyNN forward on the host cores; bounded to ~budget_s seconds of it."""
+    import random
     import sigma_zero_amd as sz
     from oracle import oracle as O
     # the GPU box exposes every host core but grants one GPU job a 16-core share; oversubscribing 256 threads
@@ -73,8 +77,10 @@ def cpu_baseline(num_searches, budget_s=15.0):
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = sz.policyNN({}).eval()
-    game = O.ChessTensor()
-    S = min(num_searches, 100)
+    random.seed(0)
+    sch = random.randint(0, 959)                       # chess_tensor.py:69
+    game = O.ChessTensor(chess960=True, scharnagl=sch)
+    S = 10
     sims = 0
     rng = np.random.RandomState(0)
     t0 = time.perf_counter()
@@ -86,8 +92,6 @@ def cpu_baseline(num_searches, budget_s=15.0):
                 x = torch.from_numpy(s.leaf_planes().astype(np.float32)).unsqueeze(0)
                 p, v = net(x, inference=True)
                 s.feed(p[0].numpy(), float(v[0, 0]))
-                if time.perf_counter() - t0 > budget_s * 1.5:
-                    break
             e, t = s.counters()
             sims += e + t
             idx, vis, moves = s.root_children()
@@ -96,11 +100,40 @@ def cpu_baseline(num_searches, budget_s=15.0):
             game.move_piece(moves[O.sample_move(vis, rng.random_sample())])
             plies += 1
             if game.get_value_and_terminated()[1]:
-                game = O.ChessTensor()
+                break                                      # the game of configs[0] ended inside the budget
     dt = time.perf_counter() - t0
     return {"value": sims / dt, "unit": "simulations/s", "cores": cores, "kind": "port",
-            "sample": "1 self-play game from the classical start position, num_searches=%d, fp32 batch-1 forward, %d plies / %d simulations in %.1f s"
-                      % (S, plies, sims, dt)}
+            "config": "BASELINE.json configs[0]: 1 self-play game, num_searches=10, Chess960 start %d (random.seed(0)), random-init fp32 network, CPU" % sch,
+            "sample": "the first %d plies / %d simulations of that game in %.1f s (batch-1 fp32 forward on %d host threads)" % (plies, sims, dt, cores)}
+
+
+def parity_config_sample(dev, B, chess960, n_searches=40):
+    """Throughput at the REFERENCE's arithmetic (network.py is fp32 end to end; no mixed precision anywhere): the same boards-per-GPU,
+    fp32 policyNN through torch/MIOpen, fp32 NCHW planes, one whole ply at a small search budget (the cost of a simulation does not
+    depend on the budget: trees stay shallow).  A bounded sample next to the bf16 headline, not the headline."""
+    import sigma_zero_amd as sz
+    from sigma_zero_amd.selfplay import SelfPlayEngine
+    torch.manual_seed(0)
+    net = sz.policyNN({}).eval().to(dev)
+    eng = SelfPlayEngine(net, {"C": 2, "num_searches": n_searches}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype=torch.float32)
+    eng.new_games([-1] * B)
+    with torch.no_grad():
+        eng.begin()
+        p, v = eng.evaluate(eng.planes)                    # warm-up forward (MIOpen algorithm search) outside the timed region
+        torch.cuda.synchronize(dev)
+        st0 = eng.stats()
+        t0 = time.perf_counter()
+        eng.search()
+        eng.play(np.random.RandomState(7).random_sample(B))
+        eng.fetch_ply()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    st1 = eng.check_errors()
+    eng.close()
+    sims = st1["simulations"] - st0["simulations"]
+    return {"value": sims / dt, "unit": "simulations/s", "dtype": "f32", "network": "policyNN fp32 (torch / MIOpen), NCHW fp32 planes",
+            "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, n_searches, sims, dt),
+            "search_level_gap_of_bf16": "profiles/r02a_bf16_vs_fp32_search_S{100,800}.json (tests/test_gpu_train_and_precision.py)"}
 
 
 def main():
@@ -119,6 +152,7 @@ def main():
                     help="network-input image written by the tree kernel on the fast path: bit-packed (1 KiB/board) or bf16 NHWC (16 KiB/board)")
     ap.add_argument("--edges-per-board", type=int, default=0, help="child slots per board (0 = engine default: worst case when it fits in half of the free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-config", action="store_true", help="skip the fp32-network sample (`parity_config`)")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
 
@@ -212,6 +246,8 @@ def main():
 
     sims = st1["simulations"] - st0["simulations"]
     exps = st1["expansions"] - st0["expansions"]
+    # every board ran a full search in every timed ply (finished games are refilled, the counters survive the refill)
+    assert sims == B * S * a.steps, "simulation counter %d != boards x searches x steps = %d" % (sims, B * S * a.steps)
     sum_depth = st1["sum_depth"] - st0["sum_depth"]
     sum_k = st1["sum_children"] - st0["sum_children"]
     from sigma_zero_amd.train_rl import aggregate_throughput
@@ -282,8 +318,11 @@ def main():
             else:
                 out["roofline"] = tree_roof
                 out["roofline_nn"] = nn_roof
+        if not a.no_parity_config and world == 1 and fast:
+            eng.close()
+            out["parity_config"] = parity_config_sample(dev, B, a.chess960)
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (bounded ~15 s sample)
-            out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
