@@ -5,7 +5,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libsigmazero_hip.so")
+LIB = os.environ.get("SIGMAZERO_LIB") or os.path.join(PKG, "libsigmazero_hip.so")      # SIGMAZERO_LIB: A/B runs of two builds of the library on one GPU box
 SOURCES = ["sz_engine.hip", "sz_nn.hip", "sz_host.cpp"]
 HEADERS = [os.path.join(CSRC, "sz_chess.h"), os.path.join(PKG, "..", "include", "sigmazero.h")]
 # -ffp-contract=off: the UCB / prior arithmetic must round exactly like the reference's torch ops

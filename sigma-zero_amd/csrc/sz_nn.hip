@@ -278,15 +278,29 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
 //   weights (4 fragments per k-step) ride a 2-deep ring one k-step ahead, activations are double-buffered one
 //   half-step ahead.  Weight order: [tap][k32][co_tile16][lane][8] (sz_nn_pack_weights16).
 // =================================================================================================================
+// One weight fragment through a buffer descriptor: UNIFORM base (kernel argument -> 4 SGPRs) + uniform element offset (soffset, SGPR)
+// + the lane's constant 32-bit byte offset (voffset, one VGPR).  With flat global_load hipcc carried a 64-bit per-lane pointer per
+// weight stream and hoisted a dozen of them out of the tile loop of the persistent tower: those were its 24 spilled VGPRs (100 B/lane of
+// scratch, reloaded with vmcnt(0) waits once per tile — never inside a K loop, but serialising the first prefetch of every tile).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wfrag_rsrc(const uint4* __restrict__ w) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer, no stride; weights of one conv are < 2 MB
+}
+__device__ __forceinline__ uint4 ld_wfrag(__amdgpu_buffer_rsrc_t r, size_t uniform_off, uint32_t lane_bytes) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)(uniform_off * 16), 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // first PF k-steps of a convolution's weight stream into the ring (issued early, e.g. under the previous layer's epilogue)
 template <int RING>
 __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uint4 (&aring)[RING][4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint4* wbase = w + (size_t)(wave * 4) * 64 + lane;
+    const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+    const __amdgpu_buffer_rsrc_t wr = wfrag_rsrc(w);
 #pragma unroll
     for (int s = 0; s < RING - 1; s++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) aring[s][i] = wbase[(size_t)s * (16 * 64) + i * 64];
+        for (int i = 0; i < 4; i++) aring[s][i] = ld_wfrag(wr, (size_t)s * (16 * 64), wlane + i * 1024);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -319,7 +333,8 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     const int W_KSTEP_STRIDE = wprobe ? 0 : 16 * 64;       // uint4 per (tap,k32); 0 = timing probe: every k-step re-reads the same (L1-hot) fragments
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
-    const uint4* wbase = w + (size_t)(wave * NI) * 64 + lane;
+    const uint32_t wlane = (uint32_t)((wave * NI) * 64 + lane) * 16u;   // the lane's constant byte offset inside a k-step's 16 fragments
+    const __amdgpu_buffer_rsrc_t wr = wfrag_rsrc(w);
     // The accumulators start at the bias: the MFMAs of the very first k-step take the bias quad as their C operand (tap 0 is peeled
     // off the tap loop for that), so no accumulator is ever initialised separately (128 v_accvgpr writes per convolution otherwise).
     f32x4 binit[NI];
@@ -340,7 +355,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             if constexpr (PREFETCHED) aring[s][i] = ring_in[s][i];
-            else aring[s][i] = wbase[(size_t)s * W_KSTEP_STRIDE + i * 64];
+            else aring[s][i] = ld_wfrag(wr, (size_t)s * W_KSTEP_STRIDE, wlane + i * 1024);
         }
     // the image's offset is folded into the per-lane row address, so the k offset still fits the 16-bit immediate of ds_read for the
     // second image of the persistent tower, which sits beyond 64 KB (otherwise every read pays a v_add)
@@ -378,7 +393,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                 if (!NN_ILV) {
                     if (hs == 0 && ks + PF < TOTAL_KS) {        // weights PF k-steps ahead (slot freed by the previous half-step)
 #pragma unroll
-                        for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + i * 64];
+                        for (int i = 0; i < NI; i++) aring[(kc + PF) & (RING - 1)][i] = ld_wfrag(wr, (size_t)(ks + PF) * W_KSTEP_STRIDE, wlane + i * 1024);
                     }
                     // activations of the next half-step
                     if (hs == 0) {
@@ -412,7 +427,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             } else if (m < NH + NI) {
                                 if (ABL & 1) {}
                                 else if (hs == 0 && ks + PF < TOTAL_KS)
-                                    aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)(ks + PF) * W_KSTEP_STRIDE + (m - NH) * 64];
+                                    aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(ks + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
                             }
                             asm volatile("" ::: "memory");
                             __builtin_amdgcn_sched_barrier(0);
@@ -449,7 +464,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             else bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m]);            // first fragments of phase B
                         } else if (m < NH + NI) {
                             const int vks = ks + PF, wks = vks < TOTAL_KS ? vks : vks - KSTEPS;              // phase B re-reads this tap's weights
-                            if (!(ABL & 1)) aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)wks * W_KSTEP_STRIDE + (m - NH) * 64];
+                            if (!(ABL & 1)) aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)wks * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
                         } else if (kc == KSTEPS - 1 && (m == 2 * NH || m == 3 * NH)) {
                             epi0(m == 2 * NH ? 0 : 1, -1);                                                     // stage -1: operand prefetch for the first two tiles
                         }
@@ -471,7 +486,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             if (!(ABL & 2) && kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m] + (kc + 1) * 64);
                         } else if (m < NH + NI) {
                             if (!(ABL & 1) && kc + PF < KSTEPS)
-                                aring[(kc + PF) & (RING - 1)][m - NH] = wbase[(size_t)(tap * KSTEPS + kc + PF) * W_KSTEP_STRIDE + (m - NH) * 64];
+                                aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(tap * KSTEPS + kc + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
                         } else {
                             // 16 tiles of the first half over 8 k-steps: two per k-step, each in four stages of one or two instructions
                             // (gaps 8..11 and 12..15), so that a gap never carries more than an MFMA leaves free

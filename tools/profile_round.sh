@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-config > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
 cp $(find /tmp/prof_$TAG/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
 echo "stats done"
 for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU"; do
