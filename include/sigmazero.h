@@ -58,6 +58,10 @@ typedef struct sz_config {
                                   * HBM (no position can overflow), else what fits, at least num_searches*64+256 */
     int32_t planes_dtype;        /* SZ_PLANES_F32 / SZ_PLANES_BF16: element type of the network input */
     int32_t device;              /* HIP device ordinal */
+    int32_t reuse_subtree;       /* NON-REFERENCE option, 0 = off (default, the reference builds a fresh tree per ply: sim.py:53).  != 0: sz_play keeps the
+                                  * subtree below the move it plays (compacted in place) and the next sz_search_begin continues on it — the new root starts
+                                  * with that child's visit count, value sum and children — whenever the kept part is at most num_searches nodes and half
+                                  * of the child slots; otherwise, and after sz_new_games / sz_upload_game, the search starts fresh.  Doubles the stores. */
 } sz_config;
 
 typedef struct sz_stats {

@@ -15,7 +15,7 @@ SZ_NN_IN_BITS = 0x1000000
 class sz_config(C.Structure):
     _fields_ = [("n_boards", C.c_int32), ("num_searches", C.c_int32), ("c_puct", C.c_float), ("learning", C.c_int32),
                 ("noise_value", C.c_float), ("chess960", C.c_int32), ("edges_per_board", C.c_int32),
-                ("planes_dtype", C.c_int32), ("device", C.c_int32)]
+                ("planes_dtype", C.c_int32), ("device", C.c_int32), ("reuse_subtree", C.c_int32)]
 
 
 class sz_stats(C.Structure):

@@ -44,13 +44,15 @@ struct alignas(16) Ctl {
     int status, n_nodes, n_edges, sims_done;
     int pend_node, pend_depth, game_ply, err;
     unsigned long long n_expand, n_term, sum_depth, sum_k;
-    int max_edges, game_result, pad0, pad1;
+    int max_edges, game_result, reuse_ready, pad1;      // reuse_ready: the store holds the subtree of the move just played (sz_config.reuse_subtree)
 };
 
 struct View {
     int B, S, n_cap, e_cap, p_cap, learning, chess960, planes_dtype;
     float c_puct, noise;
     unsigned long long* dbg;    // diagnostic (sz_debug_step_stamps): 8 u64 per board, s_memtime at the phase boundaries of k_search_step; NULL = off
+    int reuse;                  // NON-REFERENCE option (sz_config.reuse_subtree): keep the chosen child's subtree as the next search's tree
+    int* nmap;                  // reuse only: [B][n_cap] scratch map node id -> new index of the edge that owns it, during k_play's compaction
     const int* slot;            // optional (sz_compact): row of board b in the network batch (planes / policy / value); NULL = identity
     const float* root_gamma;    // optional (non-reference) true Dirichlet root noise: [B][SZ_MAX_MOVES] Gamma(alpha,1) draws; NULL = reference behaviour
     SzPos* npos; SzPos* ring; EdgeStat* es; EdgeMeta* em; int* gpath; u64* pmask; Ctl* ctl;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(64) void k_new_games(View v, const int* scharnagl, 
     if (lane_id() == 0) {
         bp.ring[0] = X;
         Ctl c = *bp.ctl;                                  // the cumulative counters (n_expand, n_term, sum_depth, sum_k, max_edges) survive a refill
-        c.status = ST_ACTIVE; c.n_nodes = c.n_edges = c.sims_done = 0; c.pend_node = c.pend_depth = c.game_ply = c.err = 0; c.game_result = 0;
+        c.status = ST_ACTIVE; c.n_nodes = c.n_edges = c.sims_done = 0; c.pend_node = c.pend_depth = c.game_ply = c.err = 0; c.game_result = 0; c.reuse_ready = 0;
         *bp.ctl = c;
     }
 }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(1024) void k_compact(View v, int* slot, int* n_live
 __global__ void k_after_upload(View v, int b, int ply) {
     Ctl* c = v.ctl + b;
     Ctl z = *c;                                           // cumulative counters kept, per-game fields reset
-    z.status = ST_ACTIVE; z.n_nodes = z.n_edges = z.sims_done = 0; z.pend_node = z.pend_depth = z.err = 0; z.game_result = 0; z.game_ply = ply;
+    z.status = ST_ACTIVE; z.n_nodes = z.n_edges = z.sims_done = 0; z.pend_node = z.pend_depth = z.err = 0; z.game_result = 0; z.game_ply = ply; z.reuse_ready = 0;
     *c = z;
 }
 
@@ -404,7 +406,23 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
     const int root_ply = uni(bp.ctl->game_ply);
     SzPos X = load_pos(bp.ring + (root_ply & (SZ_RING - 1)));
     path[0] = 0;
+    if (v.reuse && uni(bp.ctl->reuse_ready) && uni(bp.ctl->n_nodes) <= v.S && 2 * (long long)uni(bp.ctl->n_edges) <= v.e_cap && v.S > 0) {
+        // NON-REFERENCE option: the store already holds the subtree below the move just played (k_play compacted it to the front: edge 0 /
+        // node 0 = that child, now the root, with its visit count and value sum).  The search continues on it: nothing to expand here, so
+        // the board does not wait for the network; sz_search_begin's descent-only launch selects its first leaf.
+        wave_load_history(bp, path, 0, root_ply, X, hist);
+        __syncthreads();
+        wave_encode(hist, X, nullptr, v.planes_dtype, v.rec_planes ? v.rec_planes + (size_t)b * SZ_NUM_PLANES * 8 : nullptr);   // training record of the root only
+        if (lane == 0) {
+            bp.npos[0] = X;
+            Ctl* c = bp.ctl;
+            c->status = (status & ST_ACTIVE) | ST_SEARCHING; c->sims_done = 0; c->pend_node = -1; c->pend_depth = 0; c->reuse_ready = 0;
+            if (v.rec_colour) v.rec_colour[b] = (uint8_t)szm_turn(X.meta);
+        }
+        return;
+    }
     if (lane == 0) {
+        bp.ctl->reuse_ready = 0;
         bp.npos[0] = X;
         EdgeStat s; s.W = 0.0; s.N = 1; s.P = 0.f;                 // root.visit_count = 1 (mcts.py:46)
         bp.es[0] = s;
@@ -457,6 +475,7 @@ __global__ __launch_bounds__(64, 4) void k_search_step(View v, const float* __re
     const int root_ply = uni(bp.ctl->game_ply);
     const int row = v.slot ? uni(v.slot[b]) : b;              // network batch row of this board
     if (row < 0) return;
+    if ((status & ST_PENDING) && !policy) return;             // descent-only launch (sz_search_begin with reuse): boards that already wait for the network sit it out
     unsigned long long n_expand = 0, n_term = 0, sum_depth = 0, sum_k = 0;
     int err = 0;
     STEP_STAMP(0);
@@ -710,6 +729,50 @@ __global__ __launch_bounds__(64) void k_play(View v, const double* uniforms) {
         c->game_result = result;
         if (v.rec_nchild) { v.rec_nchild[b] = n; v.rec_chosen[b] = action; v.rec_over[b] = (uint8_t)over; v.rec_result[b] = (int8_t)result; v.rec_active[b] = 1; }
     }
+    if (!v.reuse || over) return;
+    // ---- NON-REFERENCE option: keep the subtree of the move just played (the reference builds a fresh tree per ply, sim.py:53) ------------
+    // Spans are bump-allocated in node-creation order and a node is created after its parent, so walking the nodes in id order visits the kept
+    // spans in ascending address order: every span moves DOWN (destination <= source), in place, no second buffer.  nmap[nid] = new index of the
+    // edge that owns node nid (-1 = not in the kept subtree); the chosen child becomes edge 0 / node 0.
+    __syncthreads();
+    const int n_nodes = uni(bp.ctl->n_nodes);
+    const EdgeMeta cm = bp.em[first + chosen];
+    const int nid_c = uni(cm.node), n_c = uni((int)cm.n);
+    if (nid_c < 0 || n_c == 0) return;                               // never visited, or a leaf: nothing to keep (reuse_ready stays 0)
+    int* nmap = v.nmap + (size_t)b * v.n_cap;
+    for (int i = lane; i < n_nodes; i += 64) nmap[i] = -1;
+    const EdgeStat cs = bp.es[first + chosen];
+    __threadfence_block();
+    if (lane == 0) { bp.es[0] = cs; bp.em[0] = cm; nmap[nid_c] = 0; }
+    __threadfence_block();
+    int cursor = 1, new_nid = 0;
+    for (int nid = nid_c; nid < n_nodes; nid++) {
+        const int e_new = uni(nmap[nid]);
+        if (e_new < 0) continue;
+        EdgeMeta m = bp.em[e_new];                                   // already moved; `first` still points at the old span, which no copy has reached yet
+        const int ofirst = uni(m.first), on = uni((int)m.n);
+        for (int base = 0; base < on; base += 64) {
+            const int k = base + lane;
+            EdgeStat s2; EdgeMeta m2;
+            if (k < on) { s2 = bp.es[ofirst + k]; m2 = bp.em[ofirst + k]; }
+            __threadfence_block();
+            if (k < on) {
+                bp.es[cursor + k] = s2; bp.em[cursor + k] = m2;
+                if (m2.node >= 0) nmap[m2.node] = cursor + k;
+            }
+            __threadfence_block();
+        }
+        if (lane == 0) {
+            SzPos pz = bp.npos[nid];
+            bp.npos[new_nid] = pz;
+            bp.em[e_new].first = on > 0 ? cursor : -1;
+            bp.em[e_new].node = new_nid;
+        }
+        __threadfence_block();
+        cursor += on;
+        new_nid++;
+    }
+    if (lane == 0) { Ctl* c = bp.ctl; c->n_nodes = new_nid; c->n_edges = cursor; c->reuse_ready = 1; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -790,13 +853,14 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
     View& v = e->v;
     memset(&v, 0, sizeof v);
     v.B = cfg->n_boards; v.S = cfg->num_searches;
-    v.n_cap = cfg->num_searches + 2;
+    v.reuse = cfg->reuse_subtree ? 1 : 0;
+    v.n_cap = (v.reuse ? 2 : 1) * cfg->num_searches + 2;     // reuse: up to num_searches kept nodes + num_searches new ones
     if (cfg->edges_per_board > 0) {
         v.e_cap = cfg->edges_per_board;
     } else {
         // default: the worst case (every expansion creates the maximum of 218 children) when it fits in half of the free HBM, so that no
         // position can overflow a search (4096 boards x 800 searches: 22.9 GB of the 288 GB); otherwise what fits, at least 64 per search
-        const long long worst = (long long)cfg->num_searches * SZ_MAX_MOVES + 2, floor_cap = (long long)cfg->num_searches * 64 + 256;
+        const long long worst = (long long)(v.reuse ? 2 : 1) * cfg->num_searches * SZ_MAX_MOVES + 2, floor_cap = (long long)cfg->num_searches * 64 + 256;
         size_t free_b = 0, total_b = 0;
         long long fit = floor_cap;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -806,7 +870,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
         v.e_cap = (int)cap;
     }
     if (v.e_cap < SZ_MAX_CHILDREN + 2) v.e_cap = SZ_MAX_CHILDREN + 2;
-    v.p_cap = cfg->num_searches + 2;
+    v.p_cap = v.n_cap;
     v.learning = cfg->learning; v.chess960 = cfg->chess960; v.planes_dtype = cfg->planes_dtype;
     v.c_puct = cfg->c_puct; v.noise = cfg->noise_value; v.root_gamma = nullptr; v.dbg = nullptr;
     e->lds_bytes = (LDS_HIST_WORDS + LDS_MASK_WORDS) * 8 + (size_t)(v.p_cap > 256 ? v.p_cap : 256) * 4 + 220 * 4 + 220 * 2;   // + expand stash
@@ -819,6 +883,7 @@ int sz_create(const sz_config* cfg, sz_engine** out) {
         (rc = dalloc(e, &v.rec_action, B * SZ_MAX_CHILDREN)) || (rc = dalloc(e, &v.rec_visits, B * SZ_MAX_CHILDREN)) ||
         (rc = dalloc(e, &v.rec_nchild, B)) || (rc = dalloc(e, &v.rec_colour, B)) || (rc = dalloc(e, &v.rec_chosen, B)) ||
         (rc = dalloc(e, &v.rec_over, B)) || (rc = dalloc(e, &v.rec_result, B)) || (rc = dalloc(e, &v.rec_active, B)) ||
+        (v.reuse && (rc = dalloc(e, &v.nmap, B * v.n_cap))) ||
         (rc = dalloc(e, &e->d_scharnagl, B)) || (rc = dalloc(e, &e->d_active, B)) || (rc = dalloc(e, &e->d_slot, B)) || (rc = dalloc(e, &e->d_nlive, 1))) {
         sz_destroy(e);
         return rc;
@@ -908,6 +973,12 @@ int sz_search_begin(sz_engine* e, void* planes_dev, void* stream) {
     ENGINE_GUARD(e);
     hipLaunchKernelGGL(k_search_begin, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, planes_dev);
     HIPCHK(hipGetLastError());
+    if (e->v.reuse && planes_dev) {
+        // boards that continue on a kept subtree have no root to evaluate: one descent-only launch selects their first leaf (boards whose fresh
+        // root waits for the network sit it out), so that every board enters the first network call with a real position
+        hipLaunchKernelGGL(k_search_step, dim3(e->v.B), dim3(64), e->lds_bytes, (hipStream_t)stream, e->v, (const float*)nullptr, (const float*)nullptr, planes_dev);
+        HIPCHK(hipGetLastError());
+    }
     return SZ_OK;
 }
 

@@ -53,7 +53,7 @@ class SelfPlayEngine:
         self.bits = planes_dtype == "bits128"
         code = N.SZ_PLANES_NHWC128_BITS if self.bits else N.SZ_PLANES_NHWC128_BF16 if self.nhwc else (N.SZ_PLANES_BF16 if planes_dtype == torch.bfloat16 else N.SZ_PLANES_F32)
         cfg = N.sz_config(self.B, self.S, float(args["C"]), int(bool(learning)), float(noise_value), int(self.chess960),
-                          int(edges_per_board), code, self.device.index or 0)
+                          int(edges_per_board), code, self.device.index or 0, int(bool(self.args.get("reuse_subtree", False))))
         self._e = C.c_void_p()
         N.check(N.lib().sz_create(C.byref(cfg), C.byref(self._e)), "sz_create")
         dev = self.device

@@ -160,3 +160,75 @@ def test_refill_and_compaction_give_identical_per_game_records():
     assert st_plain["sims"] == st_packed["sims"]                       # the same work was done ...
     assert st_packed["nn_rows"] <= st_packed["sims"] + 10 * 2 * st_packed["plies"]      # ... on network batches that held (almost) only live boards
     assert st_plain["nn_rows"] == 12 * 10 * st_plain["plies"]
+
+
+# ------------------------------------------------------------------------------------------------ 4. subtree reuse (non-reference option)
+def _subtree_rows(tree, root_child_action):
+    """rows of the DFS dump below the root child with that action index, depths shifted so that its children are depth 0"""
+    d, a, v, w, p = tree
+    k0 = next(k for k in range(1, len(d)) if d[k] == 0 and a[k] == root_child_action)
+    k1 = next((k for k in range(k0 + 1, len(d)) if d[k] == 0), len(d))
+    return (int(v[k0]), float(w[k0])), (d[k0 + 1:k1] - 1, a[k0 + 1:k1], v[k0 + 1:k1], w[k0 + 1:k1], p[k0 + 1:k1])
+
+
+def test_subtree_reuse_option_carries_the_chosen_subtree_exactly_and_default_is_off():
+    """optional reuse of the search tree across plies (the reference builds a fresh tree per ply, sim.py:53 — default).
+    With args['reuse_subtree'] the tree at the start of ply p+1 must be EXACTLY the subtree below the move played at ply p (same nodes,
+    visits, value sums, priors, child order), and the next search adds num_searches simulations on top of it."""
+    from test_gpu_parity import random_evaluator
+    S, B = 48, 16
+    sch = [17 * b + 3 for b in range(B)]
+
+    def run(reuse, plies=3):
+        args = {"C": 2, "num_searches": S}
+        if reuse:
+            args["reuse_subtree"] = True
+        eng = SelfPlayEngine(None, args, B, chess960=True, learning=True)
+        eng.new_games(sch)
+        ev = random_evaluator(123)
+        urng = np.random.RandomState(9)
+        out = []
+        for ply in range(plies):
+            eng.begin()
+            torch.cuda.synchronize()
+            start = [eng.debug_tree(b) for b in range(B)]
+            for step in range(S):
+                policy, value = ev(eng.planes, step)
+                eng.step(policy, value)
+            st = eng.check_errors()
+            end = [eng.debug_tree(b) for b in range(B)]
+            eng.play(urng.random_sample(B))
+            rec = eng.fetch_ply()
+            out.append((start, end, rec, st))
+        eng.close()
+        return out
+
+    fresh = run(False)
+    for start, end, rec, st in fresh:                                  # default: every ply starts from a bare root (visit_count 1, mcts.py:46)
+        for b in range(B):
+            assert len(start[b][0]) == 1 and start[b][2][0] == 1
+            assert end[b][2][0] == 1 + S
+    kept = run(True)
+    n_reused = 0
+    for ply in range(1, len(kept)):
+        prev_end, rec_prev = kept[ply - 1][1], kept[ply - 1][2]
+        start, end = kept[ply][0], kept[ply][1]
+        for b in range(B):
+            (n_c, w_c), sub = _subtree_rows(prev_end[b], int(rec_prev["chosen"][b]))
+            d, a, v, w, p = start[b]
+            if len(sub[0]) == 0:                                       # the played move was never expanded: nothing to keep, fresh root
+                assert len(d) == 1 and v[0] == 1
+                continue
+            n_reused += 1
+            assert (int(v[0]), float(w[0])) == (n_c, w_c), "ply %d board %d root stats" % (ply, b)
+            assert np.array_equal(d[1:], sub[0]) and np.array_equal(a[1:], sub[1]) and np.array_equal(v[1:], sub[2]), "ply %d board %d subtree" % (ply, b)
+            assert np.array_equal(w[1:], sub[3]) and np.array_equal(p[1:].view(np.uint32), sub[4].view(np.uint32))
+            # the search continued on it: exactly S more simulations through the root, children account for all but the root's own first visit
+            de, ae, ve, we, pe = end[b]
+            assert ve[0] == n_c + S
+            assert ve[1:][de[1:] == 0].sum() == n_c - 1 + S
+            # ply 1's records are those of the fresh run (the first search is identical with or without the option)
+    assert n_reused >= B // 2
+    for b in range(B):
+        assert np.array_equal(kept[0][2]["visits"][b], fresh[0][2]["visits"][b]) and kept[0][2]["chosen"][b] == fresh[0][2]["chosen"][b]
+    assert kept[-1][3]["simulations"] == fresh[-1][3]["simulations"] == B * S * len(kept)
