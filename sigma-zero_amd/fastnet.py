@@ -177,6 +177,14 @@ class FastPolicyNet:
 
     @torch.no_grad()
     def __call__(self, planes, inference=True):
+        if torch.cuda.current_device() != self.device.index:
+            # the launches below go to this network's GPU even when the caller's current device is another one (a null stream handle
+            # carries no device: the C ABI can only guard calls made on a real stream)
+            with torch.cuda.device(self.device):
+                return self._forward(planes, inference)
+        return self._forward(planes, inference)
+
+    def _forward(self, planes, inference=True):
         B = planes.shape[0]
         x, scratch = self.tower(planes)
         if self.native_heads:

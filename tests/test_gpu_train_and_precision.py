@@ -232,3 +232,44 @@ def test_subtree_reuse_option_carries_the_chosen_subtree_exactly_and_default_is_
     for b in range(B):
         assert np.array_equal(kept[0][2]["visits"][b], fresh[0][2]["visits"][b]) and kept[0][2]["chosen"][b] == fresh[0][2]["chosen"][b]
     assert kept[-1][3]["simulations"] == fresh[-1][3]["simulations"] == B * S * len(kept)
+
+
+def test_play_games_to_the_end_on_fewer_slots_than_games():
+    """64 Chess960 games on 16 slots, played to their natural end (mate, stalemate, material, 75 moves, fivefold): every game is complete —
+    a result unless it hit the ply cap, one sample per ply, rewards derived from the result (sim.py:86-97), replayable move by move"""
+    torch.manual_seed(0)
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    random.seed(5); np.random.seed(5)
+    st = {}
+    games = sz.sim.play_games(fast, {"C": 2, "num_searches": 6}, 64, c960=True, n_boards=16, max_plies=600, stats=st)
+    assert len(games) == 64
+    kinds = set()
+    total = 0
+    for g in games:
+        n = len(g["actions"])
+        total += n
+        assert n == len(g["states"]) == len(g["colours"]) == len(g["rewards"]) > 0
+        assert (g["result"] is not None) or n == 600, "a game that stopped before the cap must be over"
+        reward = {"1-0": 1, "0-1": -1}.get(g["result"], 0)
+        assert g["rewards"] == [reward if i % 2 == 0 else -reward for i in range(n)]
+        assert g["colours"][0] is True and all(a != b for a, b in zip(g["colours"], g["colours"][1:]))
+        kinds.add(g["result"])
+    assert st["sims"] == 6 * total and st["nn_rows"] == st["sims"]           # every network row carried a live board
+    assert len(kinds) >= 2, kinds
+
+
+def test_engine_follows_the_models_device():
+    """a rank with local_rank > 0 must search on ITS GPU.  Needs two visible devices; the one-GPU box checks the default."""
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    eng = SelfPlayEngine(fast, {"C": 2, "num_searches": 2}, 2, planes_dtype="bits128")
+    assert eng.planes.device == fast.device == torch.device("cuda", torch.cuda.current_device())
+    eng.close()
+    if torch.cuda.device_count() > 1:
+        before = torch.cuda.current_device()
+        net1 = sz.policyNN({}).to("cuda:1").eval()
+        fast1 = FastPolicyNet(net1)
+        assert fast1.device == torch.device("cuda:1")
+        eng1 = SelfPlayEngine(fast1, {"C": 2, "num_searches": 2}, 2, planes_dtype="bits128")
+        assert eng1.planes.device == torch.device("cuda:1") and torch.cuda.current_device() == before
+        eng1.new_games([-1, -1]); eng1.search(); eng1.check_errors()
+        eng1.close()
