@@ -347,8 +347,54 @@ def gen_play():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["games", "search", "play"]
-    games = gen_games() if ("games" in which or "search" in which) else None
+    games = gen_games() if ("games" in which or "search" in which or "realnet" in which) else None
     if "search" in which:
         gen_search(games)
     if "play" in which:
         gen_play()
+
+
+# --------------------------------------------------------------------------- D. the north-star statement itself: reference mcts.py + reference network.py (CPU, fp32)
+def gen_real_network(games):
+    """MCTS0.search of the reference with the reference's own policyNN (torch.manual_seed(0) random init, eval mode, fp32, CPU, batch 1 —
+    exactly what `python mcts.py` / `python sim.py` run) on real positions.  The product must reproduce the visit distributions with ITS
+    network module (same seed -> same weights, golden-checked) on the GPU: 'within 1e-4 fp32, move indices bit-exact' (BASELINE.json north_star)."""
+    import network as ref_net
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    net = ref_net.policyNN({})
+    net.eval()
+    rs = random.Random(2024)
+    spec = [(0, 0, 30, False), (0, 0, 100, True), (0, 5, 60, True), (1, 9, 60, False), (9, 4, 60, True), (3, 6, 40, True), (4, 12, 50, False)]
+    n_scripted = len(SCRIPTED)
+    for k in range(7):
+        gi = n_scripted + rs.randrange(len(games) - n_scripted)
+        spec.append((gi, rs.randrange(0, max(1, len(games[gi]["moves"]) - 1)), [40, 80][k % 2], bool(k % 2)))
+    cases = []
+    for ci, (gi, ply, S, learning) in enumerate(spec):
+        game = replay(games, gi, ply)
+        if game.board.is_game_over():
+            ply -= 1
+            game = replay(games, gi, ply)
+        torch.manual_seed(100 + ci)
+        t0 = time.time()
+        engine = ref_mcts.MCTS0(game=game, args={"C": 2, "num_searches": S}, model=net)
+        probs = engine.search(game.board, verbose=False, learning=learning)
+        with torch.no_grad():
+            p0, v0 = net(game.get_representation().float().unsqueeze(0), inference=True)
+        root_actions = [ref_ct.actionToTensor(m, game.board.turn).nonzero().item() for m in probs.keys()]
+        cases.append(dict(game=gi, ply=ply, S=S, learning=int(learning), root_actions=np.array(root_actions, np.int32),
+                          root_probs=np.array(list(probs.values()), np.float64),
+                          root_moves=np.array([(m.from_square, m.to_square, m.promotion or 0) for m in probs.keys()], np.int32).reshape(-1, 3),
+                          root_policy=p0[0].numpy().copy(), root_value=np.float32(v0.item())))
+        print("real-network case %2d: game %2d ply %3d S=%3d learning=%d -> %d children, %.1fs" % (ci, gi, ply, S, learning, len(probs), time.time() - t0))
+    flat = {"n_cases": np.int64(len(cases)), "torch_version": np.array(torch.__version__)}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat["c%d_%s" % (i, k)] = np.array(v) if not isinstance(v, np.ndarray) else v
+    np.savez_compressed(os.path.join(OUT, "chess_real_network_searches.npz"), **flat)
+    torch.set_num_threads(1)
+
+
+if __name__ == "__main__" and "realnet" in sys.argv[1:]:
+    gen_real_network(games if games is not None else gen_games())

@@ -260,3 +260,28 @@ def test_device_select_on_reference_ucb_vectors_bitwise(golden_dir):
     got = ucb.cpu().numpy()
     assert np.array_equal(got.view(np.uint32), z["ucb"].view(np.uint32))
     assert np.array_equal(arg.cpu().numpy().astype(np.int64), z["argmax"])
+
+
+# ------------------------------------------------------------------------------------------------ E. the north-star statement: reference CPU path vs the GPU engine
+def test_gpu_engine_with_fp32_network_matches_reference_cpu_path(games, golden_dir):
+    """Fixture: the reference's mcts.py + the reference's policyNN (seed 0, fp32, CPU, batch 1).  Here: MCTS0 of the product = HIP engine +
+    the product's policyNN on the GPU (fp32 through MIOpen).  Move indices must be exact; visit fractions within 1e-4 (BASELINE.json north_star)."""
+    z = _load(golden_dir, "chess_real_network_searches.npz")
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    worst, n_exact, n = 0.0, 0, 0
+    for i, case in _cases(z):
+        ct = _host_game(games, int(case["game"]), int(case["ply"]))
+        with torch.no_grad():
+            p0, v0 = net(ct.get_representation().float().unsqueeze(0).cuda(), inference=True)
+        assert np.allclose(p0[0].cpu().numpy(), case["root_policy"], rtol=1e-3, atol=1e-8) and abs(float(v0) - float(case["root_value"])) < 1e-4
+        m = sz.MCTS0(game=ct, args={"C": 2, "num_searches": int(case["S"])}, model=net)
+        probs = m.search(ct.board, verbose=False, learning=bool(case["learning"]))
+        assert [(k.from_square, k.to_square, k.promotion or 0) for k in probs] == [tuple(int(x) for x in r) for r in case["root_moves"]], "case %d: moves" % i
+        d = float(np.abs(np.array(list(probs.values())) - case["root_probs"]).max())
+        worst = max(worst, d)
+        n_exact += int(d == 0.0)
+        n += 1
+        assert d <= 1e-4, "case %d: visit fractions differ by %.3g (one visit = %.3g)" % (i, d, 1.0 / (int(case["S"]) - 1))
+    print("reference CPU path vs GPU engine + fp32 network: %d/%d searches with identical visit counts, worst |delta fraction| %.2e" % (n_exact, n, worst))
+    assert n >= 14

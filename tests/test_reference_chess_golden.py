@@ -219,3 +219,33 @@ def test_scharnagl_draw_is_pythons_random(golden_dir):
             random.seed(int(case["seed"]))
             want = np.atleast_1d(case["scharnagl"]).tolist()
             assert [random.randint(0, 959) for _ in want] == want
+
+
+# ------------------------------------------------------------------------------------------------ D. reference mcts.py + reference network.py
+def test_oracle_with_product_network_matches_reference_cpu_path(games, golden_dir):
+    """BASELINE.json north_star: 'visit-count policies and values matching the reference CPU path within 1e-4 fp32 (move indices bit-exact)
+    on fixed seeds'.  Fixture = the reference's mcts.py driving the reference's policyNN (seed 0, fp32, CPU).  Here: the oracle search driving
+    the PRODUCT's policyNN (same seed -> same weights) on the CPU."""
+    import torch
+    import sigma_zero_amd as sz
+    z = _load(golden_dir, "chess_real_network_searches.npz")
+    torch.manual_seed(0)
+    net = sz.policyNN({}).eval()
+    n = 0
+    for i, case in _cases(z):
+        ct = _oracle_game(games, int(case["game"]), int(case["ply"]))
+        with torch.no_grad():
+            p0, v0 = net(torch.from_numpy(ct.get_representation().astype(np.float32)).unsqueeze(0), inference=True)
+        assert np.allclose(p0[0].numpy(), case["root_policy"], rtol=1e-4, atol=1e-9) and abs(float(v0) - float(case["root_value"])) < 1e-5
+
+        def ev(planes):
+            with torch.no_grad():
+                p, v = net(torch.from_numpy(planes.astype(np.float32)).unsqueeze(0), inference=True)
+            return p[0].numpy(), float(v[0, 0])
+        s = O.search_with_evaluator(ct, ev, c=2.0, num_searches=int(case["S"]), learning=bool(case["learning"]))
+        idx, vis, moves = s.root_children()
+        assert idx == case["root_actions"].tolist(), "case %d: move indices" % i
+        assert [m.key() for m in moves] == [tuple(int(x) for x in r) for r in case["root_moves"]]
+        assert np.abs(np.array(vis, np.float64) / sum(vis) - case["root_probs"]).max() <= 1e-4, "case %d: visit fractions" % i
+        n += 1
+    assert n >= 14
