@@ -398,3 +398,29 @@ def gen_real_network(games):
 
 if __name__ == "__main__" and "realnet" in sys.argv[1:]:
     gen_real_network(games if games is not None else gen_games())
+
+
+# --------------------------------------------------------------------------- E. BASELINE.json configs[0] itself: `python sim.py` (sim.py:125-137)
+def gen_config0():
+    """1 self-play game, num_searches=10, Chess960, random-init policyNN on the CPU — the reference's own runnable case, with the seeds fixed."""
+    import network as ref_net
+    torch.set_num_threads(8)
+    seed = 0
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    net = ref_net.policyNN({})
+    net.eval()
+    state = random.getstate()
+    sch = random.randint(0, 959)
+    random.setstate(state)
+    t0 = time.time()
+    with quiet():
+        h = ref_sim.generate_training_data(net, 1, {"C": 2, "num_searches": 10}, None, True)
+    c = pack_history(h)
+    c.update(seed=seed, c960=1, S=10, scharnagl=sch, kind="config0")
+    print("configs[0]: Chess960 start %d, %d plies, %.1fs" % (sch, len(h["actions"]), time.time() - t0))
+    np.savez_compressed(os.path.join(OUT, "chess_config0_game.npz"), **{k: (np.array(v) if not isinstance(v, np.ndarray) else v) for k, v in c.items()})
+    torch.set_num_threads(1)
+
+
+if __name__ == "__main__" and "config0" in sys.argv[1:]:
+    gen_config0()

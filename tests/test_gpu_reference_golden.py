@@ -285,3 +285,24 @@ def test_gpu_engine_with_fp32_network_matches_reference_cpu_path(games, golden_d
         assert d <= 1e-4, "case %d: visit fractions differ by %.3g (one visit = %.3g)" % (i, d, 1.0 / (int(case["S"]) - 1))
     print("reference CPU path vs GPU engine + fp32 network: %d/%d searches with identical visit counts, worst |delta fraction| %.2e" % (n_exact, n, worst))
     assert n >= 14
+
+
+def test_config0_whole_game_matches_reference(golden_dir):
+    """BASELINE.json configs[0] — the reference's own runnable case (`python sim.py`, sim.py:125-137: 1 self-play game, num_searches=10,
+    Chess960, random-init policyNN; the reference ran it on the CPU in fp32 with seed 0): the product plays the SAME game on the GPU (HIP engine +
+    fp32 policyNN), all 361 plies: start position, every state, every visit distribution, every sampled move, rewards."""
+    case = _load(golden_dir, "chess_config0_game.npz")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    h = sz.generate_training_data(net, 1, {"C": 2, "num_searches": 10}, None, True)
+    n_ref = len(case["rewards"])
+    # report how far the two games agree before asserting (a single flipped visit would change a sampled move sooner or later)
+    agree = 0
+    for k in range(min(len(h["actions"]), n_ref)):
+        a, b = case["act_off"][k], case["act_off"][k + 1]
+        if not np.array_equal(pack_planes(h["states"][k].numpy()), case["states"][k]) or list(h["actions"][k].values()) != case["act_probs"][a:b].tolist():
+            break
+        agree += 1
+    print("configs[0] game: %d of %d plies identical to the reference's CPU run" % (agree, n_ref))
+    assert len(h["actions"]) == n_ref and agree == n_ref
+    _check_history(h, case)

@@ -249,3 +249,29 @@ def test_oracle_with_product_network_matches_reference_cpu_path(games, golden_di
         assert np.abs(np.array(vis, np.float64) / sum(vis) - case["root_probs"]).max() <= 1e-4, "case %d: visit fractions" % i
         n += 1
     assert n >= 14
+
+
+def test_config0_game_prefix_with_product_network_on_cpu(golden_dir):
+    """BASELINE.json configs[0] (`python sim.py`: 1 game, num_searches=10, Chess960, random-init network, CPU) as played by the reference
+    with seed 0: the oracle driving the product's policyNN on the CPU replays its first 60 plies sample for sample (the GPU test plays all 361)."""
+    import torch
+    import sigma_zero_amd as sz
+    case = _load(golden_dir, "chess_config0_game.npz")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    net = sz.policyNN({}).eval()
+    assert random.randint(0, 959) == int(case["scharnagl"])
+    ct = O.ChessTensor(chess960=True, scharnagl=int(case["scharnagl"]))
+    for k in range(60):
+        assert np.array_equal(pack_planes(ct.get_representation()), case["states"][k]), "ply %d" % k
+
+        def ev(planes):
+            with torch.no_grad():
+                p, v = net(torch.from_numpy(planes.astype(np.float32)).unsqueeze(0), inference=True)
+            return p[0].numpy(), float(v[0, 0])
+        s = O.search_with_evaluator(ct, ev, c=2.0, num_searches=10, learning=True)
+        idx, vis, moves = s.root_children()
+        a, b = case["act_off"][k], case["act_off"][k + 1]
+        assert [m.key() for m in moves] == [tuple(int(x) for x in r) for r in case["act_moves"][a:b]], "ply %d" % k
+        assert [v / sum(vis) for v in vis] == case["act_probs"][a:b].tolist(), "ply %d" % k
+        assert ct.turn == int(case["colours"][k])
+        ct.move_piece(moves[O.sample_move(vis, np.random.random_sample())])
