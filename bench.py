@@ -108,32 +108,47 @@ def cpu_baseline(budget_s=15.0):
 
 
 def parity_config_sample(dev, B, chess960, n_searches=40):
-    """Throughput at the REFERENCE's arithmetic (network.py is fp32 end to end; no mixed precision anywhere): the same boards-per-GPU,
-    fp32 policyNN through torch/MIOpen, fp32 NCHW planes, one whole ply at a small search budget (the cost of a simulation does not
-    depend on the budget: trees stay shallow).  A bounded sample next to the bf16 headline, not the headline."""
+    """Throughput at the REFERENCE's precision (network.py is fp32 end to end; no mixed precision anywhere), same boards-per-GPU, one whole
+    ply at a small search budget (the cost of a simulation does not depend on the budget: trees stay shallow).  Two legs:
+      value / torch_fp32  fp32 policyNN through torch/MIOpen on fp32 NCHW planes — the reference's arithmetic itself;
+      mfma_split          the same weights on the matrix cores with every operand split into two bf16 numbers and three MFMAs per product
+                          (SplitPolicyNet / k_tower16_split, f32 accumulation, f32 heads): reproduces the fp32 network's SEARCH results
+                          (tests: 64/64 boards identical visit counts, the configs[0] game ply for ply).
+    Bounded samples next to the bf16 headline, not the headline."""
     import sigma_zero_amd as sz
     from sigma_zero_amd.selfplay import SelfPlayEngine
+    from sigma_zero_amd.fastnet import SplitPolicyNet
     torch.manual_seed(0)
     net = sz.policyNN({}).eval().to(dev)
-    eng = SelfPlayEngine(net, {"C": 2, "num_searches": n_searches}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype=torch.float32)
-    eng.new_games([-1] * B)
-    with torch.no_grad():
-        eng.begin()
-        p, v = eng.evaluate(eng.planes)                    # warm-up forward (MIOpen algorithm search) outside the timed region
-        torch.cuda.synchronize(dev)
-        st0 = eng.stats()
-        t0 = time.perf_counter()
-        eng.search()
-        eng.play(np.random.RandomState(7).random_sample(B))
-        eng.fetch_ply()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-    st1 = eng.check_errors()
-    eng.close()
-    sims = st1["simulations"] - st0["simulations"]
-    return {"value": sims / dt, "unit": "simulations/s", "dtype": "f32", "network": "policyNN fp32 (torch / MIOpen), NCHW fp32 planes",
-            "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, n_searches, sims, dt),
-            "search_level_gap_of_bf16": "profiles/r02a_bf16_vs_fp32_search_S{100,800}.json (tests/test_gpu_train_and_precision.py)"}
+
+    def one(model, planes_dtype, S):
+        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype=planes_dtype)
+        eng.new_games([-1] * B)
+        with torch.no_grad():
+            eng.begin()
+            eng.evaluate(eng.planes)                           # warm-up forward (MIOpen algorithm search) outside the timed region
+            torch.cuda.synchronize(dev)
+            st0 = eng.stats()
+            t0 = time.perf_counter()
+            eng.search()
+            eng.play(np.random.RandomState(7).random_sample(B))
+            eng.fetch_ply()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        st1 = eng.check_errors()
+        eng.close()
+        return st1["simulations"] - st0["simulations"], dt
+
+    sims, dt = one(net, torch.float32, n_searches)
+    out = {"value": sims / dt, "unit": "simulations/s", "dtype": "f32", "network": "policyNN fp32 (torch / MIOpen), NCHW fp32 planes",
+           "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, n_searches, sims, dt),
+           "search_level_gap_of_bf16": "profiles/r02a_bf16_vs_fp32_search_S{100,800}.json (tests/test_gpu_train_and_precision.py)"}
+    S2 = 4 * n_searches
+    sims2, dt2 = one(SplitPolicyNet(net, device=dev), "bits128", S2)
+    out["mfma_split"] = {"value": sims2 / dt2, "unit": "simulations/s", "dtype": "bf16x2 operands (hi + lo), 3 MFMAs per product, f32 accumulate, f32 heads",
+                         "network": "SplitPolicyNet: k_tower16_split + fp32 GEMM heads",
+                         "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, S2, sims2, dt2)}
+    return out
 
 
 def main():
@@ -145,8 +160,8 @@ def main():
     ap.add_argument("--searches", type=int, default=800)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chess960", type=int, default=0)
-    ap.add_argument("--net", default="fast", choices=["fast", "torch"],
-                    help="fast: hand-written MFMA conv tower (csrc/sz_nn.hip); torch: MIOpen/ATen kernels")
+    ap.add_argument("--net", default="fast", choices=["fast", "torch", "split"],
+                    help="fast: hand-written bf16 MFMA tower (csrc/sz_nn.hip); split: the same on hi+lo bf16 operands (reference precision class); torch: MIOpen/ATen kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--planes", default="bits128", choices=["bits128", "nhwc128"],
                     help="network-input image written by the tree kernel on the fast path: bit-packed (1 KiB/board) or bf16 NHWC (16 KiB/board)")
@@ -178,11 +193,12 @@ def main():
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    fast = a.net == "fast" and dtype == torch.bfloat16
+    split = a.net == "split"
+    fast = (a.net == "fast" and dtype == torch.bfloat16) or split
     B, S = a.boards, a.searches
     if fast:
-        from sigma_zero_amd.fastnet import FastPolicyNet
-        model = FastPolicyNet(sz.policyNN({}).eval(), device=dev)
+        from sigma_zero_amd.fastnet import FastPolicyNet, SplitPolicyNet
+        model = SplitPolicyNet(sz.policyNN({}).eval().to(dev), device=dev) if split else FastPolicyNet(sz.policyNN({}).eval(), device=dev)
         eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=a.planes, edges_per_board=a.edges_per_board)
     else:
         model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
@@ -257,7 +273,7 @@ def main():
         out = {
             "metric": "MCTS simulations/sec (self-play)", "value": total_sims / dt_max, "unit": "simulations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / max(a.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2" if split else ("bf16" if dtype == torch.bfloat16 else "f32"),
             "data": "synthetic (seeded random-init policyNN weights, self-play from %s start positions)" % ("Chess960" if a.chess960 else "classical"),
             "config": {"workload": "selfplay_%dboards_%dsearches" % (B, S), "boards_per_gpu": B, "num_searches": S, "C": 2,
                        "learning": True, "chess960": bool(a.chess960), "step": "one ply = full search of every board + sample + play",
@@ -295,19 +311,20 @@ def main():
                 # per launch, or k_conv_bf16<256,9> when block fusion is off
                 conv_ms = float(np.mean([s.elapsed_time(e) for s, e in conv_events]))
                 fused = getattr(model, "fuse_blocks", False)
-                whole = getattr(model, "persistent_tower", False) and B <= getattr(model, "persistent_max_boards", 0)
+                whole = split or (getattr(model, "persistent_tower", False) and B <= getattr(model, "persistent_max_boards", 0))
                 conv_flop = 2.0 * B * 64 * 256 * 2304 * (2 if fused else 1)
                 if whole:                                   # stem (119 real input planes) + 38 tower convolutions in one launch
-                    conv_flop = 2.0 * B * 64 * 256 * 9 * (119 + 38 * 256)
+                    conv_flop = 2.0 * B * 64 * 256 * 9 * (119 + 38 * 256)          # ALGORITHMIC flop (the split tower spends 3 MFMAs per product: not counted)
                 ctf = conv_flop / (conv_ms * 1e-3) / 1e12
                 traffic, traffic_src = None, None          # HBM bytes per launch from committed rocprofv3 --pmc passes
                 try:
                     with open(os.path.join(ROOT, "profiles", "pmc_tower_latest.json" if whole else "pmc_conv_latest.json")) as f:
                         traffic_src = json.load(f)
-                    traffic = traffic_src["hbm_bytes_per_launch"] if ((fused or whole) and B == 4096 and (not whole or traffic_src.get("planes") == a.planes)) else None
+                    traffic = traffic_src["hbm_bytes_per_launch"] if ((fused or whole) and not split and B == 4096 and (not whole or traffic_src.get("planes") == a.planes)) else None
                 except Exception:
                     pass
-                out["roofline"] = {"kernel": "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole
+                out["roofline"] = {"kernel": "k_tower16_split (persistent, hi+lo bf16 operands: 3 MFMAs per algorithmic product)" if split
+                                   else "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole
                                    else "k_block16_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU, 16x16x32 MFMA)" if fused
                                    else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,

@@ -193,6 +193,12 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
  * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128). */
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
+/* The same tower at the REFERENCE's precision class (network.py is fp32 end to end) on the matrix cores: every operand carried as two bf16 numbers
+ * (hi + lo, 16 bits of mantissa), every product as three MFMAs with f32 accumulation.  w_hi / w_lo: HOST arrays of 1 + 2*n_blocks DEVICE pointers to the
+ * hi = bf16(w) and lo = bf16(w - hi) parts of the BatchNorm-folded weights, each packed by sz_nn_pack_weights16; out [n_boards,64,256] F32 NHWC (the heads
+ * then run in fp32).  About 3x the time of sz_nn_tower_bf16, about 100x closer to the fp32 network. */
+int sz_nn_tower_split(const void* planes, const void* const* w_hi, const void* const* w_lo, const float* const* bias, int32_t n_blocks, float* out,
+                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
 /* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records
  * s_memtime at the phase boundaries of one block (tools/tower_stamps.py); NULL switches back to the shipped kernel */
 int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);

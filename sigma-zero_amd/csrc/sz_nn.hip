@@ -317,6 +317,7 @@ __device__ __forceinline__ int conv_tap_addr16(int tap, int j, int p16, int kg) 
 }
 
 template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */,
+          bool ACCUM = false /* add onto the accumulators as they are (second / third pass of a split-precision convolution): no bias, no initialisation */,
           class EPI = std::nullptr_t /* callable (p, stage): stage -1..3 of the epilogue of accumulator tile p = i*NH + j of the FIRST position half (EpiTile16 /
                                         EpiResidual16); when given, the LAST tap runs its two position halves one after the other and the epilogue of the first
                                         half rides in the MFMA gaps of the second */>
@@ -341,7 +342,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
     for (int i = 0; i < NI; i++) binit[i] = bias ? *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool PEEL = RING == 4;                       // 512-register tower only: the peeled copy costs the 256-register kernels spills
-    if (skip || !PEEL) {
+    if ((skip || !PEEL) && !ACCUM) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
@@ -502,7 +503,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     };
     if (!skip) {
         if constexpr (PEEL) {
-            tap_body(0, std::true_type{});
+            tap_body(0, std::integral_constant<bool, !ACCUM>{});
             for (int tap = 1; tap < (SPLIT ? NTAPS - 1 : NTAPS); tap++) tap_body(tap, std::false_type{});
             last_tap_split();
         } else {
@@ -1084,6 +1085,105 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
     }
 }
 
+// =================================================================================================================
+// Split-precision tower: the reference-precision inference path on the matrix cores.  network.py is fp32 end to end; bf16 MFMA operands keep
+// 8 bits of mantissa.  Here every operand is carried as TWO bf16 numbers, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 bits of
+// mantissa), and a product is three MFMAs with f32 accumulation:  w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi  (the dropped lo*lo term is
+// 2^-16 relative) — about 100x closer to the fp32 network than the bf16 tower, at a third of its speed, still 7x the fp32 torch/MIOpen forward.
+// Same persistent structure as k_tower16_bf16, but ONE board per workgroup: the activations x and t live in LDS as four images
+// (x_hi, x_lo, t_hi, t_lo: 4 x 35 KB).  A convolution is three passes of the same K loop over (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi) onto
+// one set of accumulators; the residual is added in f32 from hi + lo.  Output: the tower activation as f32 [n_boards][64][256] (the heads
+// then run in fp32).  Input planes are 0/1: their lo part is zero, the stem needs two passes only.
+// =================================================================================================================
+struct TowerSplitParams {
+    const uint4* wh[NN_MAX_CONVS];                         // hi parts, sz_nn_pack_weights16 order ([0] = stem, C_in padded to 128)
+    const uint4* wl[NN_MAX_CONVS];                         // lo parts
+    const float* b[NN_MAX_CONVS];
+};
+
+// v = relu(acc [+ (x_hi + x_lo)]) of accumulator tile (i, j) -> hi / lo images (every lane owns 4 channels of one position)
+template <bool RESID>
+__device__ __forceinline__ void split_tile_to_lds(unsigned char* hi_img, unsigned char* lo_img, const f32x4 (&acc)[4][4], int i, int j) {
+    constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+    uint2* ph = (uint2*)(hi_img + row * OPITCH + co * 2);
+    uint2* pl = (uint2*)(lo_img + row * OPITCH + co * 2);
+    f32x4 v = acc[i][j];
+    if (RESID) {
+        const uint2 rh = *ph, rl = *pl;
+        v[0] += bf16_lo(rh.x) + bf16_lo(rl.x); v[1] += bf16_hi(rh.x) + bf16_hi(rl.x);
+        v[2] += bf16_lo(rh.y) + bf16_lo(rl.y); v[3] += bf16_hi(rh.y) + bf16_hi(rl.y);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    uint2 h, l;
+    h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]);
+    l.x = pack_bf16x2(v[0] - bf16_lo(h.x), v[1] - bf16_hi(h.x));
+    l.y = pack_bf16x2(v[2] - bf16_lo(h.y), v[3] - bf16_hi(h.y));
+    *ph = h; *pl = l;
+}
+
+__global__ __launch_bounds__(256, 1) void k_tower16_split(const uint16_t* __restrict__ planes, TowerSplitParams prm, float* __restrict__ out, int n_boards, int n_blocks, int flags) {
+    constexpr int WGB = 1;
+    constexpr int PITCH = NN_COUT * 2 + NN_PAD16;
+    constexpr int IMG = WGB * 64 * PITCH + NN_ZERO16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* Xh = lds;
+    unsigned char* Xl = lds + IMG;
+    unsigned char* Th = lds + 2 * IMG;
+    unsigned char* Tl = lds + 3 * IMG;
+    for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256)
+#pragma unroll
+        for (int im = 0; im < 4; im++) *(uint4*)(lds + im * IMG + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    int* addr_tab = (int*)(lds + 4 * IMG);
+    for (int e = threadIdx.x; e < 9 * 4 * WGB * 64; e += 256)
+        addr_tab[e] = conv_tap_addr16<PITCH, 9, WGB>(e / (4 * WGB * 64), (e >> 6) % (4 * WGB), e & 15, (e >> 4) & 3);
+    f32x4 acc[4][4 * WGB];
+    for (int tile = blockIdx.x; tile < n_boards; tile += gridDim.x) {
+        __syncthreads();                                               // previous tile's images fully read
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(Th, planes, tile, n_boards);
+        else stage_tile<128, WGB, NN_PAD16>(Th, planes, tile, n_boards, false);
+        __syncthreads();
+        // stem: planes are exact in bf16 (0 / 1), so x_lo = 0: w_hi*x + w_lo*x
+        conv_kloop16<128, 9, WGB, 4, false, 0, false>(lds, prm.wh[0], acc, false, false, nullptr, 2 * IMG, prm.b[0]);
+        conv_kloop16<128, 9, WGB, 4, false, 0, true>(lds, prm.wl[0], acc, false, false, nullptr, 2 * IMG, nullptr);
+#pragma unroll
+        for (int j = 0; j < 4 * WGB; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) split_tile_to_lds<false>(Xh, Xl, acc, i, j);
+        __syncthreads();
+        for (int blk = 0; blk < n_blocks; blk++) {
+            const int c1 = 1 + 2 * blk, c2 = 2 + 2 * blk;
+            // t = relu(bn1(conv1(x)))
+            conv_kloop16<256, 9, WGB, 4, false, 0, false>(lds, prm.wh[c1], acc, false, false, nullptr, 0, prm.b[c1], addr_tab);
+            conv_kloop16<256, 9, WGB, 4, false, 0, true>(lds, prm.wh[c1], acc, false, false, nullptr, IMG, nullptr, addr_tab);
+            conv_kloop16<256, 9, WGB, 4, false, 0, true>(lds, prm.wl[c1], acc, false, false, nullptr, 0, nullptr, addr_tab);
+#pragma unroll
+            for (int j = 0; j < 4 * WGB; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) split_tile_to_lds<false>(Th, Tl, acc, i, j);
+            __syncthreads();
+            // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads the x images now
+            conv_kloop16<256, 9, WGB, 4, false, 0, false>(lds, prm.wh[c2], acc, false, false, nullptr, 2 * IMG, prm.b[c2], addr_tab);
+            conv_kloop16<256, 9, WGB, 4, false, 0, true>(lds, prm.wh[c2], acc, false, false, nullptr, 3 * IMG, nullptr, addr_tab);
+            conv_kloop16<256, 9, WGB, 4, false, 0, true>(lds, prm.wl[c2], acc, false, false, nullptr, 2 * IMG, nullptr, addr_tab);
+#pragma unroll
+            for (int j = 0; j < 4 * WGB; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) split_tile_to_lds<true>(Xh, Xl, acc, i, j);
+            __syncthreads();
+        }
+        // tower output in f32 = hi + lo, coalesced 16-byte stores
+        float4* dst = (float4*)out + (size_t)tile * 64 * (NN_COUT / 4);
+        for (int idx = threadIdx.x; idx < 64 * (NN_COUT / 4); idx += 256) {
+            const int row = idx >> 6, c4 = idx & 63;
+            const uint2 h = *(const uint2*)(Xh + row * PITCH + c4 * 8), l = *(const uint2*)(Xl + row * PITCH + c4 * 8);
+            dst[idx] = make_float4(bf16_lo(h.x) + bf16_lo(l.x), bf16_hi(h.x) + bf16_hi(l.x), bf16_lo(h.y) + bf16_lo(l.y), bf16_hi(h.y) + bf16_hi(l.y));
+        }
+    }
+}
+
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)
 
 // the network entry points carry no engine handle: they run on the device that owns the caller's stream (a rank whose current
@@ -1272,6 +1372,32 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     else if (g_tower_mode == 4) TOWER_LAUNCH(4);
     else TOWER_LAUNCH(1);
 #undef TOWER_LAUNCH
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+// Split-precision tower (see k_tower16_split): w_hi / w_lo / bias are HOST arrays of 1 + 2*n_blocks DEVICE pointers (hi and lo bf16 parts of the
+// BatchNorm-folded weights, each in sz_nn_pack_weights16 order); out [n_boards,64,256] f32 NHWC.
+int sz_nn_tower_split(const void* planes, const void* const* w_hi, const void* const* w_lo, const float* const* bias, int32_t n_blocks, float* out,
+                      int32_t n_boards, int32_t flags, void* stream) {
+    if (!planes || !w_hi || !w_lo || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    TowerSplitParams prm;
+    memset(&prm, 0, sizeof prm);
+    for (int i = 0; i < 1 + 2 * n_blocks; i++) {
+        if (!w_hi[i] || !w_lo[i] || !bias[i]) return SZ_ERR_INVALID;
+        prm.wh[i] = (const uint4*)w_hi[i]; prm.wl[i] = (const uint4*)w_lo[i]; prm.b[i] = bias[i];
+    }
+    const size_t lds = 4 * ((size_t)64 * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16) + 9 * 4 * 64 * sizeof(int);   // four images + tap address table
+    static bool attr_flags[NN_MAX_DEVICES] = {};
+    bool& attr_set = attr_flags[current_device_slot()];
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int n_cu = device_cus();
+    hipLaunchKernelGGL(k_tower16_split, dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, out,
+                       n_boards, n_blocks, (int)flags);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

@@ -219,3 +219,105 @@ def planes_nchw_to_nhwc128(planes):
     out = torch.zeros(B, 64, 128, dtype=torch.bfloat16, device=planes.device)
     out[:, :, :119] = planes.reshape(B, 119, 64).transpose(1, 2).to(torch.bfloat16)
     return out
+
+
+class SplitPolicyNet:
+    """policyNN inference at the REFERENCE's precision class on the matrix cores (csrc/sz_nn.hip k_tower16_split).
+
+    network.py is fp32 end to end.  FastPolicyNet's bf16 operands keep 8 bits of mantissa (search-level effect measured in
+    tests/test_gpu_train_and_precision.py: single visits move).  Here every tower operand is carried as two bf16 numbers, x = hi + lo
+    (16 bits), every product as three MFMAs (hi*hi + hi*lo + lo*hi) with f32 accumulation, the residual and BatchNorm-folded bias in f32;
+    the heads run in fp32 through the torch module itself.  About 3x the time of the bf16 tower, ~7x faster than the fp32 torch/MIOpen
+    forward, logits within ~1e-5 relative of it.  Input: the engine's bit-packed planes ("bits128") or the bf16 NHWC image ("nhwc128")."""
+
+    def __init__(self, model, device=None):
+        model = model.eval()
+        if device is None:
+            pdev = next(model.parameters()).device
+            device = pdev if pdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        dev = self.device
+        self.model = model.to(dev).float()               # heads in fp32 (policy_head / value_head of the module)
+        self.w16 = True                                   # fragment order of the 16x16x32 kernels; play_games() picks bit-packed planes from this
+        convs = [_fold_bn(model.conv1.weight, model.norm_layer)]
+        for blk in model.resnet_blocks:
+            convs.append(_fold_bn(blk.conv1.weight, blk.bn1))
+            convs.append(_fold_bn(blk.conv2.weight, blk.bn2))
+        self.n_blocks = len(model.resnet_blocks)
+        self._keep = []
+        hi_ptrs, lo_ptrs, b_ptrs = [], [], []
+        for k, (w, b) in enumerate(convs):
+            w = w.cpu().float()
+            w_hi = w.to(torch.bfloat16).float()           # round-to-nearest-even, the same rounding the packer applies
+            w_lo = w - w_hi                               # exact in f32; rounded to bf16 by the packer
+            cin_p = 128 if k == 0 else 256
+            th, tl, tb = _pack(w_hi, cin_p, 3, dev, w16=True), _pack(w_lo, cin_p, 3, dev, w16=True), b.to(dev).contiguous()
+            self._keep += [th, tl, tb]
+            hi_ptrs.append(th.data_ptr()); lo_ptrs.append(tl.data_ptr()); b_ptrs.append(tb.data_ptr())
+        n = len(convs)
+        self._wh, self._wl, self._b = (C.c_void_p * n)(*hi_ptrs), (C.c_void_p * n)(*lo_ptrs), (C.c_void_p * n)(*b_ptrs)
+        # heads as fp32 GEMMs on the NHWC activation (BatchNorm folded in double): [B*64,256] x [256,256] -> ReLU -> x [256,73]; value 256 -> 1 -> MLP
+        wp1, bp1 = _fold_bn(model.conv_p1.weight, model.p_norm1)
+        self.h_wp1, self.h_bp1 = wp1.view(256, 256).t().contiguous().to(dev), bp1.to(dev)
+        self.h_wp2, self.h_bp2 = model.conv_p2.weight.detach().float().view(73, 256).t().contiguous().to(dev), model.conv_p2.bias.detach().float().to(dev)
+        wv, bv = _fold_bn(model.conv_v1.weight, model.v_norm)
+        self.h_wv, self.h_bv = wv.view(1, 256).t().contiguous().to(dev), bv.to(dev)
+        self.h_fc1_w, self.h_fc1_b = model.fc_v1.weight.detach().float().t().contiguous().to(dev), model.fc_v1.bias.detach().float().to(dev)
+        self.h_fc2_w, self.h_fc2_b = model.fc_v2.weight.detach().float().t().contiguous().to(dev), model.fc_v2.bias.detach().float().to(dev)
+        self.module_heads = False                         # True: run policy_head / value_head of the torch module itself (cross-check)
+        self._out, self._cap = None, 0
+        self._p = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.timing = None
+
+    def parameters(self):
+        return iter([self._p])
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def tower(self, planes):
+        """planes [B,1024] uint8 (bit-packed) or [B,64,128] bf16 -> tower activation [B,64,256] f32 (NHWC)"""
+        B = planes.shape[0]
+        if B > self._cap:
+            self._out, self._cap = torch.empty(B, 64, 256, dtype=torch.float32, device=self.device), B
+        out = self._out[:B]
+        flags = N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0
+        ev = None
+        if self.timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(N.lib().sz_nn_tower_split(C.c_void_p(planes.data_ptr()), self._wh, self._wl, self._b, self.n_blocks, C.c_void_p(out.data_ptr()), B, flags,
+                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_split")
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, planes, inference=True):
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                return self._forward(planes, inference)
+        return self._forward(planes, inference)
+
+    def _forward(self, planes, inference=True):
+        B = planes.shape[0]
+        out = self.tower(planes)
+        if self.module_heads:
+            x = out.view(B, 8, 8, 256).permute(0, 3, 1, 2)                   # logical NCHW, channels_last memory: no copy
+            policy, value = self.model.policy_head(x), self.model.value_head(x)
+        else:
+            x2 = out.view(B * 64, 256)
+            t = torch.relu(torch.addmm(self.h_bp1, x2, self.h_wp1))
+            policy = torch.addmm(self.h_bp2, t, self.h_wp2).view(B, 64, 73).transpose(1, 2).reshape(B, 73 * 64)      # flatten of [73,8,8]
+            v = torch.relu(torch.addmm(self.h_bv, x2, self.h_wv)).view(B, 64)
+            value = torch.tanh(torch.addmm(self.h_fc2_b, torch.relu(torch.addmm(self.h_fc1_b, v, self.h_fc1_w)), self.h_fc2_w))
+        if inference:
+            policy = torch.softmax(policy, dim=1)
+        return policy, value

@@ -256,12 +256,20 @@ def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
 
 
 def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True):
-    """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training."""
+    """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training.
+    fast_inference: True / "bf16" = FastPolicyNet (bf16 MFMA tower, the throughput configuration); "split" = SplitPolicyNet (hi+lo bf16
+    operands on the matrix cores: the reference's precision class, reproduces the fp32 network's search results, ~1/3 of the bf16 speed);
+    False / "fp32" = the torch module itself."""
     from .sim import play_games
-    from .fastnet import FastPolicyNet
+    from .fastnet import FastPolicyNet, SplitPolicyNet
     device = next(model.parameters()).device
     model.eval()
-    player = FastPolicyNet(model, device=device) if (fast_inference and device.type == "cuda") else model
+    if device.type != "cuda" or fast_inference in (False, "fp32"):
+        player = model
+    elif fast_inference == "split":
+        player = SplitPolicyNet(model, device=device)
+    else:
+        player = FastPolicyNet(model, device=device)
     games = play_games(player, args, n_games, c960=chess960, max_plies=args.get("max_plies", 100000))
     packed, aidx, aprob, rew = records_from_games(games)
     dl = DeviceBatches(packed, aidx, aprob, rew, batch_size=batch_size, device=device, shuffle=True)       # same batches as DataLoader + collate
@@ -315,6 +323,8 @@ def main(argv=None):
     ap.add_argument("--save-dir", default="saves")
     ap.add_argument("--games-dir", default="games")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--inference", default="bf16", choices=["bf16", "split", "fp32"],
+                    help="self-play network: bf16 MFMA tower (fast), split = hi+lo bf16 operands on the matrix cores (fp32-class results), fp32 = torch module")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     gpr = [int(x) for x in str(a.games_per_rank).split(",")]
@@ -349,7 +359,7 @@ def main(argv=None):
     np.random.seed(1000 + rank)
     for epoch in range(start_epoch, start_epoch + a.epochs):
         hist, games = run_cycle(model, optimiser, sched, args, a.games_per_rank, chess960=bool(a.chess960), sync=sync,
-                                batch_size=a.batch_size, total_steps=a.total_steps)
+                                batch_size=a.batch_size, total_steps=a.total_steps, fast_inference=a.inference)
         sync_module_state(model, average_buffers=True) if world > 1 else None
         n_samples = sum(len(g["actions"]) for g in games)
         # games/RL_960_{epoch}.pt (train_RL.py:229-241 merges every worker's games into one file): rank 0 writes its games under the

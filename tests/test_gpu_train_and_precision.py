@@ -125,6 +125,25 @@ def test_bf16_network_search_divergence_from_fp32(S):
     assert rep["mean_L1"] < 0.01 and rep["mean_KL"] < 1e-3 and rep["top_move_agreement"] >= 0.95 and rep["max_Linf"] <= 3.0 / (S - 1) + 1e-9, rep
 
 
+def test_split_precision_network_searches_like_fp32():
+    """SplitPolicyNet (reference-precision class on the matrix cores) against fp32 policyNN at search level: same 64 positions, S = 200"""
+    from sigma_zero_amd.fastnet import SplitPolicyNet
+    S = 200
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    split = SplitPolicyNet(net)
+    pos = _positions(64, seed=77)
+    a32, v32, n32 = _root_distributions(net, pos, S, torch.float32)
+    a16, v16, n16 = _root_distributions(split, pos, S, "bits128")
+    assert np.array_equal(n32, n16) and np.array_equal(a32, a16)
+    same = sum(int(np.array_equal(v32[b], v16[b])) for b in range(len(pos)))
+    worst = max(float(np.abs(v32[b] / v32[b].sum() - v16[b] / v16[b].sum()).max()) for b in range(len(pos)))
+    print("split-precision vs fp32 search: %d/64 boards with identical visit counts, worst |delta fraction| %.2e" % (same, worst))
+    with open(os.path.join("gpurun_out", "split_vs_fp32_search_S%d.json" % S), "w") as f:
+        json.dump(dict(S=S, boards=64, identical_boards=same, worst_delta_fraction=worst), f)
+    assert same >= 60 and worst <= 2.0 / (S - 1) + 1e-9
+
+
 # ------------------------------------------------------------------------------------------------ 3. ragged self-play: refill + compaction
 def test_refill_and_compaction_give_identical_per_game_records():
     """sim.py:102-123 plays exactly num_games games.  The product runs them on fewer board slots than games (slot refill) and evaluates
