@@ -305,15 +305,26 @@ __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uin
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Which 16 positions form MFMA position tile j: image row (= board*64 + position) of the tile's column p16.
+//   2-board workgroups: tile j = board ROW j of BOTH boards (lanes 0..7 board 0, 8..15 board 1).  Under the three taps that look one row up (dy = -1)
+//     tile 0 reads nothing but off-board zeros, under the three that look down tile 7 does: those 6 of 72 tap-tiles are skipped outright
+//     (conv_kloop16 SKIPROWS, 8.3 % of the MFMAs).  Eight consecutive lanes still read eight consecutive image rows: ds_read_b128 stays conflict-free.
+//   1-board workgroups: tile j = rows 2j, 2j+1 of the board (no tile is ever entirely off the board).
+template <int WGB>
+__device__ __forceinline__ int tile_row(int j, int p16) {
+    if constexpr (WGB == 2) return (p16 >> 3) * 64 + j * 8 + (p16 & 7);
+    else return (j >> 2) * 64 + (j & 3) * 16 + p16;
+}
+
 // LDS byte offset (inside its image) that lane (p16, kg) reads for position tile j under tap `tap` — see conv_kloop16 for the zero region
 template <int PITCH, int NTAPS, int WGB>
 __device__ __forceinline__ int conv_tap_addr16(int tap, int j, int p16, int kg) {
     const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
-    const int pos = (j & 3) * 16 + p16;                    // position inside its board (board = j >> 2)
+    const int row0 = tile_row<WGB>(j, p16), pos = row0 & 63;   // position inside its board (board = row0 >> 6)
     const int y = (pos >> 3) + dy, x = (pos & 7) + dx;
     const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
     const int vrow = pos + 8 * dy + dx;
-    return ok ? ((j >> 2) * 64 + y * 8 + x) * PITCH + kg * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
+    return ok ? ((row0 >> 6) * 64 + y * 8 + x) * PITCH + kg * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
 }
 
 template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */,
@@ -342,11 +353,17 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
     for (int i = 0; i < NI; i++) binit[i] = bias ? *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool PEEL = RING == 4;                       // 512-register tower only: the peeled copy costs the 256-register kernels spills
+    // 2-board tower: position tile 0 (board row 0) is idle under taps 0..2 (they read row -1), tile NJ-1 (row 7) under taps 6..8: no fragment
+    // loads, no MFMAs for them there (tile_row above).  ABL & 4 switches it off (A/B timing build).
+    constexpr bool SKIPROWS = PEEL && NTAPS == 9 && WGB == 2 && !(ABL & 4);
     if ((skip || !PEEL) && !ACCUM) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
+    } else if (SKIPROWS && !ACCUM) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[i][0] = binit[i];   // tile 0 takes no MFMA under the first tap, so the bias cannot ride in as its C operand
     }
     constexpr int PF = RING - 1;                           // weight prefetch distance in k-steps (512 matrix-pipe cycles each)
     static_assert(KSTEPS % RING == 0, "ring slots must be compile-time indices");
@@ -379,9 +396,11 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
     for (int j = 0; j < NJ; j++) { bnxt[j] = tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
 #pragma unroll
-    for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
-    auto tap_body = [&](const int tap, auto first_tag) {
+    for (int j = 0; j < NH; j++)
+        if (!(SKIPROWS && j == 0)) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
+    auto tap_body = [&](const int tap, auto first_tag, auto skip_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int SK = decltype(skip_tag)::value;          // SKIPROWS: 1 = position tile 0 idle under this tap (dy = -1), 2 = the last position tile idle (dy = +1)
         if (tap + 1 < NTAPS) {
 #pragma unroll
             for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
@@ -399,13 +418,13 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     // activations of the next half-step
                     if (hs == 0) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
+                        for (int j = 0; j < NH; j++) if (!(SK == 2 && j == NH - 1)) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
                     } else if (kc + 1 < KSTEPS) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
+                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0)) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
                     } else if (tap + 1 < NTAPS) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) bfrag[0][j] = *(const bf16x8*)(lds + abs_addr(bnxt[j]));
+                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0 && tap + 1 < 3)) bfrag[0][j] = *(const bf16x8*)(lds + abs_addr(bnxt[j]));
                     }
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
@@ -415,16 +434,17 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
-                        acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j], 0, 0, 0);
+                        if (!((SK == 1 && hs == 0 && j == 0) || (SK == 2 && hs == 1 && j == NH - 1)))
+                            acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j], 0, 0, 0);
                         if (NN_ILV) {
                             // one memory instruction per MFMA gap (an MFMA leaves 8 of its 16 cycles for other issue): first the next
                             // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2)
                             const int m = i * NH + j;
                             if (m < NH) {
-                                if (ABL & 2) {}
+                                if ((ABL & 2) || (SK == 2 && hs == 0 && m == NH - 1)) {}
                                 else if (hs == 0) bfrag[1][m] = *(const bf16x8*)(lds + bcur[NH + m] + kc * 64);
-                                else if (kc + 1 < KSTEPS) bfrag[0][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
-                                else if (tap + 1 < NTAPS) bfrag[0][m] = *(const bf16x8*)(lds + abs_addr(bnxt[m]));
+                                else if (kc + 1 < KSTEPS) { if (!(SK == 1 && m == 0)) bfrag[0][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64); }
+                                else if (tap + 1 < NTAPS) { if (!(SK == 1 && m == 0 && tap + 1 < 3)) bfrag[0][m] = *(const bf16x8*)(lds + abs_addr(bnxt[m])); }   // tile 0 is needed again from tap 3 on
                             } else if (m < NH + NI) {
                                 if (ABL & 1) {}
                                 else if (hs == 0 && ks + PF < TOTAL_KS)
@@ -462,7 +482,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                         if (m < NH) {
                             if (ABL & 2) {}
                             else if (kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
-                            else bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m]);            // first fragments of phase B
+                            else if (!(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m]);            // first fragments of phase B
                         } else if (m < NH + NI) {
                             const int vks = ks + PF, wks = vks < TOTAL_KS ? vks : vks - KSTEPS;              // phase B re-reads this tap's weights
                             if (!(ABL & 1)) aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)wks * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
@@ -481,10 +501,11 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
-                        acc[i][NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][NH + j], 0, 0, 0);
+                        if (!(SKIPROWS && j == NH - 1))                                           // the last tap looks one row down: board row 7 reads only zeros
+                            acc[i][NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][NH + j], 0, 0, 0);
                         const int m = i * NH + j;
                         if (m < NH) {
-                            if (!(ABL & 2) && kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m] + (kc + 1) * 64);
+                            if (!(ABL & 2) && kc + 1 < KSTEPS && !(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m] + (kc + 1) * 64);
                         } else if (m < NH + NI) {
                             if (!(ABL & 1) && kc + PF < KSTEPS)
                                 aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(tap * KSTEPS + kc + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
@@ -502,12 +523,20 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         }
     };
     if (!skip) {
-        if constexpr (PEEL) {
-            tap_body(0, std::integral_constant<bool, !ACCUM>{});
-            for (int tap = 1; tap < (SPLIT ? NTAPS - 1 : NTAPS); tap++) tap_body(tap, std::false_type{});
+        using SK0 = std::integral_constant<int, 0>;
+        if constexpr (SKIPROWS) {                              // taps 0..2 look one row up (tile 0 idle), 3..5 stay in the row, 6..8 look one row down (last tile idle)
+            using SK1 = std::integral_constant<int, 1>; using SK2 = std::integral_constant<int, 2>;
+            tap_body(0, std::integral_constant<bool, !ACCUM>{}, SK1{});
+            for (int tap = 1; tap < 3; tap++) tap_body(tap, std::false_type{}, SK1{});
+            for (int tap = 3; tap < 6; tap++) tap_body(tap, std::false_type{}, SK0{});
+            for (int tap = 6; tap < (SPLIT ? NTAPS - 1 : NTAPS); tap++) tap_body(tap, std::false_type{}, SK2{});
+            last_tap_split();
+        } else if constexpr (PEEL) {
+            tap_body(0, std::integral_constant<bool, !ACCUM>{}, SK0{});
+            for (int tap = 1; tap < (SPLIT ? NTAPS - 1 : NTAPS); tap++) tap_body(tap, std::false_type{}, SK0{});
             last_tap_split();
         } else {
-            for (int tap = 0; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
+            for (int tap = 0; tap < NTAPS; tap++) tap_body(tap, std::false_type{}, SK0{});
         }
     }
 }
@@ -524,7 +553,7 @@ template <int WGB> struct EpiTile16 {
         else if (st == 2) o.y = relu_bf16x2(pack_bf16x2(tv[2], tv[3]));
         else if (st == 3) {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+            const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
             *(uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2) = o;
         }
     }
@@ -535,7 +564,7 @@ template <int WGB> struct EpiResidual16 {
     __device__ __forceinline__ uint2* slot(int p) const {
         const int i = p / (2 * WGB), j = p % (2 * WGB);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+        const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
         return (uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2);
     }
     __device__ __forceinline__ void operator()(int p, int st) {
@@ -553,7 +582,7 @@ template <int WGB>
 __device__ __forceinline__ void acc_tile_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], int i, int j, bool relu) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+    const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
     const f32x4 v = acc[i][j];
     uint2 o;
     o.x = pack_bf16x2(v[0], v[1]);
@@ -566,7 +595,7 @@ template <int WGB>
 __device__ __forceinline__ void acc_tile_residual16(unsigned char* xlds, const f32x4 (&acc)[4][4 * WGB], int i, int j) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = (j >> 2) * 64 + (j & 3) * 16 + (lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
+    const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
     const f32x4 v = acc[i][j];
     uint2* px = (uint2*)(xlds + row * OPITCH + co * 2);
     const uint2 r = *px;
@@ -584,7 +613,7 @@ __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&a
     const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4 * WGB; j++) {
-        const int row = (j >> 2) * 64 + (j & 3) * 16 + p16;
+        const int row = tile_row<WGB>(j, p16);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = (wave * 4 + i) * 16 + 4 * kg;    // C layout: col = lane&15 (position), row = 4*(lane>>4) + reg (channel)
@@ -985,7 +1014,7 @@ __device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, cons
     const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4 * WGB; j++) {
-        const int row = (j >> 2) * 64 + (j & 3) * 16 + p16;
+        const int row = tile_row<WGB>(j, p16);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = (wave * 4 + i) * 16 + 4 * kg;
@@ -1025,7 +1054,7 @@ template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 
 __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags,
                                                           unsigned long long* __restrict__ stamps) {
     constexpr bool STAMP_ = MODE != 0;
-    constexpr int ABL = MODE >= 2 ? MODE - 1 : 0;
+    constexpr int ABL = MODE == 5 ? 4 : (MODE >= 2 ? MODE - 1 : 0);      // 5: stamps with the border-row skipping switched off (A/B of SKIPROWS)
     constexpr int WGB = 2;
     constexpr int IMG = WGB * 64 * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16;  // one activation image incl. its zero region
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1361,6 +1390,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
@@ -1370,6 +1400,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     else if (g_tower_mode == 2) TOWER_LAUNCH(2);
     else if (g_tower_mode == 3) TOWER_LAUNCH(3);
     else if (g_tower_mode == 4) TOWER_LAUNCH(4);
+    else if (g_tower_mode == 5) TOWER_LAUNCH(5);
     else TOWER_LAUNCH(1);
 #undef TOWER_LAUNCH
     HIPCHK(hipGetLastError());

@@ -28,8 +28,9 @@ for mode in modes:
     s = buf.cpu().numpy().reshape(256, 4, 8).astype(np.float64)
     s = s[s[:, :, 0] > 0].reshape(-1, 8)
     d = np.diff(s[:, :7], axis=1)
-    print("mode %d (%s): waves with stamps: %d" % (mode, {1: "full", 2: "no weight loads", 3: "no LDS reads", 4: "MFMA only"}[mode], len(s)))
+    print("mode %d (%s): waves with stamps: %d" % (mode, {1: "full", 2: "no weight loads", 3: "no LDS reads", 4: "MFMA only", 5: "border-row skipping OFF (all 72 tap-tiles multiply)"}[mode], len(s)))
     for i, n in enumerate(names):
         print("  %-22s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (n, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
     tot = s[:, 6] - s[:, 0]
-    print("  block total median %.0f cycles; MFMA-busy fraction %.3f" % (np.median(tot), 2 * 36864 / np.median(tot)))
+    mf = 2 * 36864 * (1.0 if mode == 5 else 66.0 / 72.0)
+    print("  block total median %.0f cycles; MFMA-busy fraction %.3f (%.0f MFMA cycles per block)" % (np.median(tot), mf / np.median(tot), mf))
