@@ -202,6 +202,8 @@ int sz_nn_tower_split(const void* planes, const void* const* w_hi, const void* c
 /* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records
  * s_memtime at the phase boundaries of one block (tools/tower_stamps.py); NULL switches back to the shipped kernel */
 int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
+/* counter calibration only (tools/fetch_calib.py): reads `bytes` of src exactly once, 16 B per lane, with flat global loads (mode 0) or buffer loads (mode 1) */
+int sz_debug_stream_read(const void* src, uint64_t bytes, int32_t mode, void* sink16, void* stream);
 /* Heads of policyNN (network.py:141-174) as two small kernels:
  *  policy: t = relu(bn(conv_p1(x))) [n_boards,64,256] bf16 -> conv_p2 + bias -> (softmax) -> probs [n_boards,4672] f32 in the
  *          reference's flatten order (plane*64 + row*8 + col); w_packed from sz_nn_pack_head16(conv_p2.weight [73,256]);

@@ -53,6 +53,7 @@ EXPORTS = {
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_tower_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sz_debug_stream_read": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sz_nn_policy_head_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_debug_step_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sz_set_root_noise": (C.c_int, [C.c_void_p, C.c_void_p]),

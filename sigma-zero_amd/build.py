@@ -24,7 +24,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("SIGMAZERO_EXTRA_FLAGS", "").split()           # A/B builds, e.g. -DNN_ROWSKIP=0 -DNN_WBUF=0
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

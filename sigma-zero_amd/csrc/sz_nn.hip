@@ -283,12 +283,26 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
 // weight stream and hoisted a dozen of them out of the tile loop of the persistent tower: those were its 24 spilled VGPRs (100 B/lane of
 // scratch, reloaded with vmcnt(0) waits once per tile — never inside a K loop, but serialising the first prefetch of every tile).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wfrag_rsrc(const uint4* __restrict__ w) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer, no stride; weights of one conv are < 2 MB
+#ifndef NN_WBUF
+#define NN_WBUF 1                                          // 0: A/B build with flat global loads for the weight stream (SIGMAZERO_EXTRA_FLAGS=-DNN_WBUF=0)
+#endif
+#ifndef NN_ROWSKIP
+#define NN_ROWSKIP 1                                       // 0: A/B build that multiplies the all-zero border-row tiles too
+#endif
+struct WSrc { __amdgpu_buffer_rsrc_t r; const uint4* p; };
+__device__ __forceinline__ WSrc wfrag_rsrc(const uint4* __restrict__ w) {
+    WSrc s;
+    s.r = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer, no stride; weights of one conv are < 2 MB
+    s.p = w;
+    return s;
 }
-__device__ __forceinline__ uint4 ld_wfrag(__amdgpu_buffer_rsrc_t r, size_t uniform_off, uint32_t lane_bytes) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)(uniform_off * 16), 0);
+__device__ __forceinline__ uint4 ld_wfrag(const WSrc& s, size_t uniform_off, uint32_t lane_bytes) {
+#if NN_WBUF
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(s.r, (int)lane_bytes, (int)(uniform_off * 16), 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *(const uint4*)((const char*)(s.p + uniform_off) + lane_bytes);
+#endif
 }
 
 // first PF k-steps of a convolution's weight stream into the ring (issued early, e.g. under the previous layer's epilogue)
@@ -296,7 +310,7 @@ template <int RING>
 __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uint4 (&aring)[RING][4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
-    const __amdgpu_buffer_rsrc_t wr = wfrag_rsrc(w);
+    const WSrc wr = wfrag_rsrc(w);
 #pragma unroll
     for (int s = 0; s < RING - 1; s++)
 #pragma unroll
@@ -346,7 +360,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;             // lane owns position p16 of each 16-position tile; kg selects k 8kg..8kg+7
     const uint32_t wlane = (uint32_t)((wave * NI) * 64 + lane) * 16u;   // the lane's constant byte offset inside a k-step's 16 fragments
-    const __amdgpu_buffer_rsrc_t wr = wfrag_rsrc(w);
+    const WSrc wr = wfrag_rsrc(w);
     // The accumulators start at the bias: the MFMAs of the very first k-step take the bias quad as their C operand (tap 0 is peeled
     // off the tap loop for that), so no accumulator is ever initialised separately (128 v_accvgpr writes per convolution otherwise).
     f32x4 binit[NI];
@@ -355,7 +369,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     constexpr bool PEEL = RING == 4;                       // 512-register tower only: the peeled copy costs the 256-register kernels spills
     // 2-board tower: position tile 0 (board row 0) is idle under taps 0..2 (they read row -1), tile NJ-1 (row 7) under taps 6..8: no fragment
     // loads, no MFMAs for them there (tile_row above).  ABL & 4 switches it off (A/B timing build).
-    constexpr bool SKIPROWS = PEEL && NTAPS == 9 && WGB == 2 && !(ABL & 4);
+    constexpr bool SKIPROWS = PEEL && NTAPS == 9 && WGB == 2 && !(ABL & 4) && NN_ROWSKIP;
     if ((skip || !PEEL) && !ACCUM) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
@@ -1429,6 +1443,35 @@ int sz_nn_tower_split(const void* planes, const void* const* w_hi, const void* c
     const int n_cu = device_cus();
     hipLaunchKernelGGL(k_tower16_split, dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, out,
                        n_boards, n_blocks, (int)flags);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+// Counter calibration (tools/fetch_calib.py, MI355X_MICROARCH.md "calibrate on a known byte count in your own access pattern"): read `n16` 16-byte
+// elements exactly once, grid-strided, 16 B per lane per instruction, with flat global loads (mode 0) or through a buffer descriptor the way the
+// tower streams its weights (mode 1); the xor of everything goes to sink so nothing is optimised away.
+__global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ src, size_t n16, int mode, uint4* __restrict__ sink) {
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (mode == 0) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) { const uint4 v = src[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+    } else {
+        // 1 GiB windows: a raw buffer's offsets are 32 bit
+        for (size_t base = 0; base < n16; base += ((size_t)1 << 26)) {
+            const size_t cnt = n16 - base < ((size_t)1 << 26) ? n16 - base : ((size_t)1 << 26);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + base), 0, 0x7FFFFFFF, 0x00020000);
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += stride) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(threadIdx.x * 16), (int)((i - threadIdx.x) * 16), 0);
+                acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+            }
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = acc;
+}
+int sz_debug_stream_read(const void* src, uint64_t bytes, int32_t mode, void* sink16, void* stream) {
+    if (!src || !sink16 || bytes < 16) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    hipLaunchKernelGGL(k_stream_read, dim3(device_cus() * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (size_t)(bytes / 16), (int)mode, (uint4*)sink16);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
