@@ -2,7 +2,7 @@
 lives in HBM and every step of the search runs in the HIP engine (one wavefront per board)."""
 import torch
 
-from .chess_tensor import ChessTensor, Move
+from .chess_tensor import ChessTensor
 from .mctsnode import Node
 from .selfplay import SelfPlayEngine, NOISE_REFERENCE, model_device
 

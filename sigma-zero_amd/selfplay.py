@@ -1,7 +1,6 @@
 """Batched self-play driver: B boards stepped in lock-step through the HIP engine with one batched
 network call per simulation.  This is the GPU counterpart of sim.py:31-99 + mcts.py:39-122."""
 import ctypes as C
-import time
 
 import numpy as np
 import torch

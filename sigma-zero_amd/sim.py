@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from .chess_tensor import ChessTensor, Move, index_to_move, QUEEN
+from .chess_tensor import index_to_move, QUEEN
 from .selfplay import SelfPlayEngine, unpack_planes, model_device
 
 device = "cuda" if torch.cuda.is_available() else "cpu"      # module global of the reference (sim.py:12); the engine itself follows the model's device

@@ -292,3 +292,23 @@ def test_engine_follows_the_models_device():
         assert eng1.planes.device == torch.device("cuda:1") and torch.cuda.current_device() == before
         eng1.new_games([-1, -1]); eng1.search(); eng1.check_errors()
         eng1.close()
+
+
+def test_run_cycle_with_split_precision_self_play_and_reuse_option():
+    """train_rl.run_cycle with the self-play network at the reference's precision class on the matrix cores (fast_inference="split"), and the
+    subtree-reuse option passed through the args dict of the product API"""
+    torch.manual_seed(0)
+    random.seed(0); np.random.seed(0)
+    net = sz.policyNN({}).cuda()
+    opt, sched = train_rl.make_optimiser(net)
+    before = net.conv1.weight.detach().clone()
+    hist, games = train_rl.run_cycle(net, opt, sched, {"C": 2, "num_searches": 4, "max_plies": 10}, n_games=8, chess960=True, batch_size=8, total_steps=0,
+                                     fast_inference="split")
+    assert len(games) == 8 and all(len(g["actions"]) == 10 for g in games) and len(hist) == 10 and np.isfinite(hist).all()
+    assert not torch.equal(before, net.conv1.weight.detach())
+    fast = FastPolicyNet(net.eval())
+    plain = sz.sim.play_games(fast, {"C": 2, "num_searches": 16}, 6, c960=True, scharnagl=[5, 6, 7, 8, 9, 10], uniforms=lambda g, p: 0.37, max_plies=6)
+    reuse = sz.sim.play_games(fast, {"C": 2, "num_searches": 16, "reuse_subtree": True}, 6, c960=True, scharnagl=[5, 6, 7, 8, 9, 10], uniforms=lambda g, p: 0.37, max_plies=6)
+    for a, b in zip(plain, reuse):
+        assert list(a["actions"][0].items()) == list(b["actions"][0].items())          # the first ply's search is the same with or without the option
+        assert all(abs(sum(d.values()) - 1.0) < 1e-12 for d in b["actions"]) and len(b["actions"]) == 6

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from hashmodel import evaluate_packed, pack_planes, unpack_planes
+from hashmodel import evaluate_packed, pack_planes
 
 
 def _load(golden_dir, name):
