@@ -97,7 +97,8 @@ int sz_set_active(sz_engine* e, const uint8_t* active, void* stream);
  * from ROW slot(b) of policy_dev / value_dev and writes its network input to ROW slot(b) of planes_dev — so the network runs on n_live
  * rows instead of n_boards.  Call between searches, after sz_play / sz_new_games / sz_set_active changed the live set (synchronises the
  * stream to return n_live).  enable == 0 restores the identity mapping (row = board), the default.  Results per board do not depend on
- * the mapping.  Per-board outputs (sz_root_children, sz_fetch_ply, sz_play's uniforms) stay indexed by board. */
+ * the mapping.  Per-board outputs (sz_root_children, sz_fetch_ply, sz_play's uniforms) stay indexed by board.  A board that becomes live
+ * without a new sz_compact has no row: sz_search_begin flags it SZ_ERR_STATE (sticky, sz_get_stats().first_error). */
 int sz_compact(sz_engine* e, int32_t enable, int32_t* n_live_out, void* stream);
 
 /* First half of MCTS0.search (mcts.py:43-75): create the roots (visit_count = 1), test them for

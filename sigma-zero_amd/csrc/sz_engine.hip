@@ -403,6 +403,11 @@ __global__ __launch_bounds__(64) void k_search_begin(View v, void* planes) {
         if (lane == 0) bp.ctl->status = status & ~(ST_PENDING | ST_DONE | ST_SEARCHING);
         return;
     }
+    if (v.slot && uni(v.slot[b]) < 0) {
+        // the board became live after the last sz_compact: it has no row in the network batch.  Refuse loudly instead of searching nothing.
+        if (lane == 0) { bp.ctl->status = (status & ~(ST_PENDING | ST_DONE | ST_SEARCHING)) | ST_ERROR; if (!bp.ctl->err) bp.ctl->err = SZ_ERR_STATE; }
+        return;
+    }
     const int root_ply = uni(bp.ctl->game_ply);
     SzPos X = load_pos(bp.ring + (root_ply & (SZ_RING - 1)));
     path[0] = 0;

@@ -312,3 +312,21 @@ def test_run_cycle_with_split_precision_self_play_and_reuse_option():
     for a, b in zip(plain, reuse):
         assert list(a["actions"][0].items()) == list(b["actions"][0].items())          # the first ply's search is the same with or without the option
         assert all(abs(sum(d.values()) - 1.0) < 1e-12 for d in b["actions"]) and len(b["actions"]) == 6
+
+
+def test_board_revived_without_recompaction_is_an_error_not_a_silent_skip():
+    from sigma_zero_amd import _native as N
+    from test_gpu_parity import random_evaluator
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": 3}, 4)
+    eng.new_games([-1] * 4)
+    eng.set_active([1, 1, 0, 1])
+    assert eng.compact() == 3
+    ev = random_evaluator(3)
+    eng.search(lambda planes: ev(planes, 0))
+    eng.check_errors()
+    eng.set_active([1, 1, 1, 1])                       # board 2 comes back, but the batch rows were not renumbered
+    eng.search(lambda planes: ev(planes, 0))
+    with pytest.raises(N.NativeError) as ei:
+        eng.check_errors()
+    assert ei.value.code == N.SZ_ERR_STATE
+    eng.close()
