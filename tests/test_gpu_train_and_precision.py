@@ -195,10 +195,10 @@ def test_subtree_reuse_option_carries_the_chosen_subtree_exactly_and_default_is_
     With args['reuse_subtree'] the tree at the start of ply p+1 must be EXACTLY the subtree below the move played at ply p (same nodes,
     visits, value sums, priors, child order), and the next search adds num_searches simulations on top of it."""
     from test_gpu_parity import random_evaluator
-    S, B = 48, 16
+    S, B = 160, 48
     sch = [17 * b + 3 for b in range(B)]
 
-    def run(reuse, plies=3):
+    def run(reuse, plies=5):
         args = {"C": 2, "num_searches": S}
         if reuse:
             args["reuse_subtree"] = True
