@@ -37,3 +37,10 @@ for amp, cl in ((False, False), (False, True), (True, False), (True, True)):
     if cl: model = model.to(memory_format=torch.channels_last)
     opt, _ = T.make_optimiser(model)
     print("fwd+bwd+Adam batch %d: amp(bf16)=%s channels_last=%s: %.2f ms" % (Bn, amp, cl, run(model, opt, amp, cl)), flush=True)
+# fp32 variants that keep the reference's arithmetic class: MIOpen find mode (benchmark), fused Adam
+for bench, fused in ((True, False), (False, True), (True, True)):
+    torch.backends.cudnn.benchmark = bench
+    model = sz.policyNN({}).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, fused=fused)
+    print("fp32 fwd+bwd+Adam batch %d: cudnn.benchmark=%s fused_adam=%s: %.2f ms" % (Bn, bench, fused, run(model, opt, False, False)), flush=True)
+torch.backends.cudnn.benchmark = False
