@@ -400,18 +400,23 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         // head of the tap); abs_addr() adds the offset where the address is first used, at the end of the tap
         return addr_tab ? addr_tab[(tap * NJ + j) * 64 + lane] : conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
     };
+    // The LDS base of the dynamic shared array is a link-time constant (0 here) that hipcc cannot fold early: reading through `lds + offset` cost one
+    // v_add_u32 v, 0, v in front of EVERY ds_read_b128 (64 per tap).  The base therefore goes into the row address once per tap, together with the
+    // image offset, and the fragments are read through LDS-address-space pointers built from that integer: address + immediate offset, no VALU.
+    const int lds_base = (int)(uint32_t)(uintptr_t)lds;
     auto abs_addr = [&](int rel) -> int {
-        int a = img_off + rel;
-        asm volatile("" : "+v"(a));                        // opaque: keeps img_off inside the VGPR (hipcc otherwise re-associates it into a per-read v_add)
+        int a = lds_base + img_off + rel;
+        asm volatile("" : "+v"(a));                        // opaque: keeps the sum inside the VGPR (hipcc otherwise re-associates it into a per-read v_add)
         return a;
     };
+    auto LD = [](int addr) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(uint32_t)addr; };
     int bcur[NJ], bnxt[NJ];
     bf16x8 bfrag[2][NH];
 #pragma unroll
     for (int j = 0; j < NJ; j++) { bnxt[j] = tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
 #pragma unroll
     for (int j = 0; j < NH; j++)
-        if (!(SKIPROWS && j == 0)) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j]);
+        if (!(SKIPROWS && j == 0)) bfrag[0][j] = LD(bcur[j]);
     auto tap_body = [&](const int tap, auto first_tag, auto skip_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int SK = decltype(skip_tag)::value;          // SKIPROWS: 1 = position tile 0 idle under this tap (dy = -1), 2 = the last position tile idle (dy = +1)
@@ -432,13 +437,13 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     // activations of the next half-step
                     if (hs == 0) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) if (!(SK == 2 && j == NH - 1)) bfrag[1][j] = *(const bf16x8*)(lds + bcur[NH + j] + kc * 64);
+                        for (int j = 0; j < NH; j++) if (!(SK == 2 && j == NH - 1)) bfrag[1][j] = LD(bcur[NH + j] + kc * 64);
                     } else if (kc + 1 < KSTEPS) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0)) bfrag[0][j] = *(const bf16x8*)(lds + bcur[j] + (kc + 1) * 64);
+                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0)) bfrag[0][j] = LD(bcur[j] + (kc + 1) * 64);
                     } else if (tap + 1 < NTAPS) {
 #pragma unroll
-                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0 && tap + 1 < 3)) bfrag[0][j] = *(const bf16x8*)(lds + abs_addr(bnxt[j]));
+                        for (int j = 0; j < NH; j++) if (!(SK == 1 && j == 0 && tap + 1 < 3)) bfrag[0][j] = LD(abs_addr(bnxt[j]));
                     }
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
@@ -456,9 +461,9 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             const int m = i * NH + j;
                             if (m < NH) {
                                 if ((ABL & 2) || (SK == 2 && hs == 0 && m == NH - 1)) {}
-                                else if (hs == 0) bfrag[1][m] = *(const bf16x8*)(lds + bcur[NH + m] + kc * 64);
-                                else if (kc + 1 < KSTEPS) { if (!(SK == 1 && m == 0)) bfrag[0][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64); }
-                                else if (tap + 1 < NTAPS) { if (!(SK == 1 && m == 0 && tap + 1 < 3)) bfrag[0][m] = *(const bf16x8*)(lds + abs_addr(bnxt[m])); }   // tile 0 is needed again from tap 3 on
+                                else if (hs == 0) bfrag[1][m] = LD(bcur[NH + m] + kc * 64);
+                                else if (kc + 1 < KSTEPS) { if (!(SK == 1 && m == 0)) bfrag[0][m] = LD(bcur[m] + (kc + 1) * 64); }
+                                else if (tap + 1 < NTAPS) { if (!(SK == 1 && m == 0 && tap + 1 < 3)) bfrag[0][m] = LD(abs_addr(bnxt[m])); }   // tile 0 is needed again from tap 3 on
                             } else if (m < NH + NI) {
                                 if (ABL & 1) {}
                                 else if (hs == 0 && ks + PF < TOTAL_KS)
@@ -495,8 +500,8 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                         const int m = i * NH + j;
                         if (m < NH) {
                             if (ABL & 2) {}
-                            else if (kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[m] + (kc + 1) * 64);
-                            else if (!(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m]);            // first fragments of phase B
+                            else if (kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = LD(bcur[m] + (kc + 1) * 64);
+                            else if (!(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = LD(bcur[NH + m]);            // first fragments of phase B
                         } else if (m < NH + NI) {
                             const int vks = ks + PF, wks = vks < TOTAL_KS ? vks : vks - KSTEPS;              // phase B re-reads this tap's weights
                             if (!(ABL & 1)) aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)wks * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
@@ -519,7 +524,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             acc[i][NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][NH + j], 0, 0, 0);
                         const int m = i * NH + j;
                         if (m < NH) {
-                            if (!(ABL & 2) && kc + 1 < KSTEPS && !(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = *(const bf16x8*)(lds + bcur[NH + m] + (kc + 1) * 64);
+                            if (!(ABL & 2) && kc + 1 < KSTEPS && !(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = LD(bcur[NH + m] + (kc + 1) * 64);
                         } else if (m < NH + NI) {
                             if (!(ABL & 1) && kc + PF < KSTEPS)
                                 aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(tap * KSTEPS + kc + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
@@ -1055,10 +1060,27 @@ __device__ __forceinline__ void acc_residual_inplace16(unsigned char* xlds, cons
 // = 80.7 % matrix-pipe busy; forward at B = 4096 7.3-7.6 ms vs 7.6-7.8 ms with per-block launches on the same box, B = 512 0.96 vs
 // 1.23 ms (an 8-wave, two-waves-per-SIMD variant lost 7 %).  FastPolicyNet uses it at every batch size.
 // =================================================================================================================
+// Phase stagger of the four waves of a persistent-tower workgroup.  After a barrier the waves run the K loop in lock-step, and every wave issues its
+// LDS fragment reads in the same 4 of 16 MFMA gaps of a half-step: 16 KiB wanted in 64 cycles from a 128 B/clk LDS.  Delaying wave w by w x 64 cycles
+// spreads the four read windows over the 256-cycle half-step.  NN_STAGGER=0 builds without it (A/B).
+#ifndef NN_STAGGER
+#define NN_STAGGER 1
+#endif
+__device__ __forceinline__ void wave_stagger() {
+#if NN_STAGGER
+    const int wave = threadIdx.x >> 6;
+    if (wave == 1) __builtin_amdgcn_s_sleep(1 * NN_STAGGER);
+    else if (wave == 2) __builtin_amdgcn_s_sleep(2 * NN_STAGGER);
+    else if (wave == 3) __builtin_amdgcn_s_sleep(3 * NN_STAGGER);
+#endif
+}
+
 #define NN_MAX_CONVS 40
 struct TowerParams {
     const uint4* w[NN_MAX_CONVS];                          // [0] stem (C_in 128), then conv1, conv2 of each block (16x16x32 fragment order)
     const float* b[NN_MAX_CONVS];
+    unsigned long long* pace;                              // 8 arrival counters, one per XCD residue class of blockIdx (XCD-paced tile rounds); NULL = off (SZ_NN_PACE=0)
+    unsigned long long pace_base;                          // arrivals per counter before this launch
 };
 
 // STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
@@ -1089,6 +1111,17 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
         conv_prefetch16<4>(prm.w[0], ring);
+        if (prm.pace && threadIdx.x == 0) {
+            // XCD-paced tile rounds: the 32 workgroups that share an XCD (blockIdx mod 8, round-robin dispatch) start every tile round together, so
+            // that a layer's weights are fetched into the XCD's 4 MB L2 once per round and hit by the other 31: FETCH_SIZE 2.3-4.5e6 -> 1.43e6 KB raw
+            // per launch = 8 XCDs x 8 rounds x 45 MB, the minimum of this design; launch time unchanged.  Bounded wait (<= 512 x 128 cycles): a
+            // workgroup that is not joined in time goes on alone, so a wrong mapping assumption or a shared GPU costs time, never progress.
+            const int grp = gridDim.x >> 3, round = (tile - blockIdx.x) / gridDim.x;
+            unsigned long long* c = prm.pace + (blockIdx.x & 7);
+            const unsigned long long target = prm.pace_base + (unsigned long long)(round + 1) * grp;
+            atomicAdd(c, 1ULL);
+            for (int spins = 0; spins < 512 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) __builtin_amdgcn_s_sleep(2);
+        }
         __syncthreads();                                               // previous tile's output image fully read
         if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(bufT, planes, board0, n_boards);
         else stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
@@ -1100,6 +1133,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         for (int blk = 0; blk < n_blocks; blk++) {
             const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
             TSTAMP(0);
+            wave_stagger();
             auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
             conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB>(bufT, acc));
             TSTAMP(1);
@@ -1111,6 +1145,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             TSTAMP(2);
             __syncthreads();
             TSTAMP(3);
+            wave_stagger();
             auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
             conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB>(bufX, acc));   // reads bufT
             TSTAMP(4);
@@ -1409,6 +1444,18 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
     const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
+    {   // XCD-paced tile rounds (see the kernel); SZ_NN_PACE=0 switches them off
+        static int pace_on = -1;
+        static unsigned long long* pace_buf[NN_MAX_DEVICES] = {};
+        static unsigned long long pace_total[NN_MAX_DEVICES] = {};
+        if (pace_on < 0) { const char* ev = getenv("SZ_NN_PACE"); pace_on = (ev && ev[0] == '0') ? 0 : 1; }
+        if (pace_on && grid.x % 8 == 0 && n_tiles % (int)grid.x == 0) {
+            const int slot = current_device_slot();
+            if (!pace_buf[slot]) { HIPCHK(hipMalloc(&pace_buf[slot], 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(pace_buf[slot], 0, 8 * sizeof(unsigned long long))); }
+            prm.pace = pace_buf[slot]; prm.pace_base = pace_total[slot];
+            pace_total[slot] += (unsigned long long)(n_tiles / (int)grid.x) * (grid.x / 8);
+        }
+    }
 #define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
     if (!g_tower_stamps) TOWER_LAUNCH(0);
     else if (g_tower_mode == 2) TOWER_LAUNCH(2);
