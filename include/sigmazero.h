@@ -191,7 +191,9 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
 /* The whole tower (network.py:176-184: stem conv + n_blocks BasicBlocks) in ONE persistent launch: a workgroup keeps its
  * boards' activations in LDS through all 1 + 2*n_blocks convolutions; only weights stream.  planes [n_boards,64,128] bf16
  * (SZ_PLANES_NHWC128_BF16; or _BITS with SZ_NN_IN_BITS), out [n_boards,64,256] bf16; w_packed / bias: HOST arrays of 1 + 2*n_blocks DEVICE pointers
- * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128). */
+ * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128).
+ * The workgroups that share an XCD start their tile rounds together (bounded wait on one arrival counter per XCD, allocated on first use), so a layer's
+ * weights cross the fabric once per XCD and round; environment SZ_NN_PACE=0 switches that off.  Results do not depend on it. */
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
 /* The same tower at the REFERENCE's precision class (network.py is fp32 end to end) on the matrix cores: every operand carried as two bf16 numbers
