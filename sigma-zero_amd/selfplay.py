@@ -213,5 +213,5 @@ def unpack_bits128(planes):
 
 def unpack_planes(packed):
     """(…,119,8) uint8 -> (…,119,8,8) bool; bit j of a byte = column j (train_RL.py:42 collatefn)."""
-    idx = np.arange(8, dtype=np.uint8)
-    return ((packed[..., None] >> idx) & 1).astype(bool)
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    return np.unpackbits(packed[..., None], axis=-1, bitorder="little").view(np.bool_)

@@ -6,23 +6,48 @@ import os
 import numpy as np
 import torch
 
-from .chess_tensor import index_to_move, QUEEN
+from .chess_tensor import Move, index_to_move, QUEEN
 from .selfplay import SelfPlayEngine, unpack_planes, model_device
 
 device = "cuda" if torch.cuda.is_available() else "cpu"      # module global of the reference (sim.py:12); the engine itself follows the model's device
 
 
+_DECODE = {}            # colour -> (from[4672], to[4672], promo[4672], maybe_queen[4672]) int arrays; from = -1 where the index leaves the board
+_MOVES = {}             # (from, to, promo) -> Move: one shared object per distinct move (treat the Moves of a record as read-only)
+
+
+def _decode_tables(colour_white):
+    """index -> (from, to, under-promotion piece) for one colour, computed once with index_to_move (tensorToAction, chess_tensor.py:309-410)"""
+    if colour_white not in _DECODE:
+        frm = np.full(4672, -1, np.int64); to = np.zeros(4672, np.int64); pr = np.zeros(4672, np.int64); mq = np.zeros(4672, bool)
+        for a in range(4672):
+            try:
+                mv = index_to_move(a, colour_white)
+            except IndexError:
+                continue
+            frm[a], to[a], pr[a] = mv.from_square, mv.to_square, mv.promotion or 0
+            plane, cell = divmod(a, 64)
+            mq[a] = plane < 56 and cell // 8 == 1 and plane // 7 in (0, 1, 7) and plane % 7 == 0       # one step up / up-diagonal from view row 1
+        _DECODE[colour_white] = (frm, to, pr, mq)
+    return _DECODE[colour_white]
+
+
 def _moves_for_record(action_idx, colour_white, packed_root):
     """Decode child action indices of one root into Move objects.  A sliding-plane move of a pawn from the
     7th to the 8th rank (mover's view rows 1 -> 0) is a queen promotion (tensorToAction + queen_promotion dict)."""
-    own_pawns = unpack_planes(packed_root[0])                 # plane 0 = mover's pawns, [row][col] in the mover's view
+    frm, to, pr, mq = _decode_tables(bool(colour_white))
+    a = np.asarray(action_idx, dtype=np.int64)
+    f, t, p = frm[a], to[a], pr[a].copy()
+    cand = mq[a]
+    if cand.any():
+        own_pawn_row1 = int(packed_root[0][1])                # plane 0 = mover's pawns, view row 1: bit j = column j
+        cols = a[cand] % 8
+        p[np.nonzero(cand)[0][((own_pawn_row1 >> cols) & 1).astype(bool)]] = QUEEN
     moves = []
-    for a in action_idx:
-        mv = index_to_move(int(a), colour_white)
-        plane, cell = divmod(int(a), 64)
-        row, col = divmod(cell, 8)
-        if plane < 56 and row == 1 and own_pawns[row, col] and plane // 7 in (0, 1, 7) and plane % 7 == 0:
-            mv.promotion = QUEEN
+    for key in zip(f.tolist(), t.tolist(), p.tolist()):
+        mv = _MOVES.get(key)
+        if mv is None:
+            mv = _MOVES[key] = Move(key[0], key[1], key[2] or None)
         moves.append(mv)
     return moves
 
@@ -62,7 +87,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     B = max(1, min(int(n_games), int(n_boards) if n_boards else int(n_games)))
     S = int(args["num_searches"])
     eng = SelfPlayEngine(model, args, B, chess960=c960, learning=learning, planes_dtype=planes_dtype, device=dev)
-    games = [dict(states=[], actions=[], rewards=[], colours=[], result=None) for _ in range(n_games)]
+    games = [dict(states=[], actions=[], rewards=[], colours=[], result=None, packed_states=[]) for _ in range(n_games)]   # packed_states: the (119,8) uint8 form (train_RL.py:42)
     slot_game = np.full(B, -1, dtype=np.int64)            # game running on each board slot, -1 = none
     plies = np.zeros(n_games, dtype=np.int64)             # plies played so far per game
     next_game = 0
@@ -85,16 +110,19 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
 
     def absorb(rec, game_of_slot):
         """host-side bookkeeping of one ply's records (sim.py:71-73); runs while the GPU searches the next ply"""
-        for s_ in np.nonzero((game_of_slot >= 0) & rec["active"].astype(bool))[0]:
+        slots = np.nonzero((game_of_slot >= 0) & rec["active"].astype(bool))[0]
+        if not len(slots):
+            return
+        states = torch.from_numpy(unpack_planes(rec["packed"][slots]))          # one unpack for the whole ply; a game's state is a view of it
+        for i, s_ in enumerate(slots.tolist()):
             g = int(game_of_slot[s_])
             k = int(rec["n_child"][s_])
             white = bool(rec["colour"][s_])
-            acts = rec["action"][s_, :k]
             vis = rec["visits"][s_, :k].astype(np.int64)
-            total = int(vis.sum())
-            moves = _moves_for_record(acts, white, rec["packed"][s_])
-            games[g]["states"].append(torch.from_numpy(unpack_planes(rec["packed"][s_])))
-            games[g]["actions"].append({m: int(v) / total for m, v in zip(moves, vis)})
+            moves = _moves_for_record(rec["action"][s_, :k], white, rec["packed"][s_])
+            games[g]["states"].append(states[i])
+            games[g]["packed_states"].append(rec["packed"][s_])
+            games[g]["actions"].append(dict(zip(moves, (vis / int(vis.sum())).tolist())))      # int / int in float64: the reference's v / sum_values
             games[g]["colours"].append(white)
             if rec["game_over"][s_]:
                 games[g]["result"] = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}[int(rec["result"][s_])]

@@ -90,8 +90,9 @@ def records_from_games(games):
     packed, aidx, aprob, rew = [], [], [], []
     w = (1 << np.arange(8)).astype(np.uint8)
     for g in games:
-        for st, act, r, col in zip(g["states"], g["actions"], g["rewards"], g["colours"]):
-            packed.append((st.numpy().astype(np.uint8) * w).sum(-1).astype(np.uint8))
+        pre = g.get("packed_states")                       # play_games() keeps the engine's own bit-packed record next to the bool tensor
+        for i, (st, act, r, col) in enumerate(zip(g["states"], g["actions"], g["rewards"], g["colours"])):
+            packed.append(pre[i] if pre else (st.numpy().astype(np.uint8) * w).sum(-1).astype(np.uint8))
             aidx.append(np.array([action_index(m, col) for m in act], dtype=np.int64))
             aprob.append(np.array(list(act.values()), dtype=np.float64))
             rew.append(r)
