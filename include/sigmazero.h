@@ -196,12 +196,23 @@ int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded
  * weights cross the fabric once per XCD and round; environment SZ_NN_PACE=0 switches that off.  Results do not depend on it. */
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
-/* The same tower at the REFERENCE's precision class (network.py is fp32 end to end) on the matrix cores: every operand carried as two bf16 numbers
- * (hi + lo, 16 bits of mantissa), every product as three MFMAs with f32 accumulation.  w_hi / w_lo: HOST arrays of 1 + 2*n_blocks DEVICE pointers to the
- * hi = bf16(w) and lo = bf16(w - hi) parts of the BatchNorm-folded weights, each packed by sz_nn_pack_weights16; out [n_boards,64,256] F32 NHWC (the heads
- * then run in fp32).  About 3x the time of sz_nn_tower_bf16, about 100x closer to the fp32 network. */
-int sz_nn_tower_split(const void* planes, const void* const* w_hi, const void* const* w_lo, const float* const* bias, int32_t n_blocks, float* out,
-                      int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
+/* The same tower at the REFERENCE's precision class (network.py:176-184 is fp32 end to end) on the matrix cores: every operand carried as two bf16
+ * numbers (hi = bf16(x), lo = bf16(x - hi): 16 bits of mantissa), every product as three MFMAs (hi*hi + lo*hi + hi*lo) with f32 accumulation, bias /
+ * residual / ReLU in f32.  w_stream: ONE device buffer with the weights of the whole tower in k-step order, built on the host with
+ * sz_nn_pack_split_stream (sz_nn_split_stream_elems(n_blocks) bf16 elements); bias: device [1 + 2*n_blocks][256] f32 (BatchNorm folded);
+ * out [n_boards,64,256] F32 NHWC (the heads then run in fp32).  Two boards per workgroup when n_boards exceeds the number of CUs, else one; a
+ * board's result does not depend on which (SZ_NN_SPLIT_WGB1 / _WGB2 force one form: tests).  About 100x closer to the fp32 network than
+ * sz_nn_tower_bf16 at about 2.5x its time. */
+#define SZ_NN_SPLIT_WGB1 0x2000000
+#define SZ_NN_SPLIT_WGB2 0x4000000
+int sz_nn_tower_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out,
+                      int32_t n_boards, int32_t flags /* SZ_NN_IN_BITS | SZ_NN_SPLIT_WGB* */, void* stream);
+/* host: number of bf16 elements of the weight stream; one convolution (conv 0 = stem, cin_real 119; conv c >= 1: the c-th 256-channel 3x3
+ * convolution in forward order) from the torch weight [256,cin_real,3,3] f32 into its place in the stream */
+int64_t sz_nn_split_stream_elems(int32_t n_blocks);
+int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t conv, uint16_t* stream);
+/* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */
+int sz_nn_debug_split_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
 /* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records
  * s_memtime at the phase boundaries of one block (tools/tower_stamps.py); NULL switches back to the shipped kernel */
 int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);

@@ -10,6 +10,7 @@ SZ_OK, SZ_ERR_INVALID, SZ_ERR_HIP, SZ_ERR_CAPACITY, SZ_ERR_NO_DEVICE, SZ_ERR_STA
 SZ_PLANES_F32, SZ_PLANES_BF16, SZ_PLANES_NHWC128_BF16, SZ_PLANES_NHWC128_BITS = 0, 1, 2, 3
 SZ_NN_W16 = 0x40000
 SZ_NN_IN_BITS = 0x1000000
+SZ_NN_SPLIT_WGB1, SZ_NN_SPLIT_WGB2 = 0x2000000, 0x4000000
 
 
 class sz_config(C.Structure):
@@ -52,7 +53,10 @@ EXPORTS = {
     "sz_nn_conv_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "sz_nn_block_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_tower_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "sz_nn_tower_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sz_nn_tower_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sz_nn_debug_split_stamps": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sz_nn_split_stream_elems": (C.c_int64, [C.c_int32]),
+    "sz_nn_pack_split_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_debug_stream_read": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sz_nn_policy_head_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_debug_step_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1,0 +1,358 @@
+// sz_nn_split.hip — split-precision tower: the reference-precision inference path on the matrix cores
+// (/root/reference/network.py:36-83 BasicBlock, :105-137 stem/tower, :176-184 forward).
+//
+// network.py is fp32 end to end; bf16 MFMA operands keep 8 bits of mantissa.  Here every operand is carried as TWO bf16 numbers,
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 bits of mantissa), and a product is three MFMAs with f32 accumulation:
+//     w*x ~= w_hi*x_hi + w_lo*x_hi + w_hi*x_lo          (the dropped lo*lo term is 2^-16 relative)
+// about 100x closer to the fp32 network than the bf16 tower, and it reproduces the fp32 network's SEARCH results (tests).
+//
+// Round-3 design (k_tower_split<WGB>), built around what bounded the round-2 kernel (one board per workgroup, three separate passes of the
+// bf16 K loop: every weight fragment fetched once per 16 MFMAs = 64 B/clk/CU of L2 traffic, the most a CU gets):
+//   * persistent, one workgroup (4 waves, one per SIMD) per CU takes a tile of WGB boards through all 39 convolutions;
+//   * TWO boards per workgroup at large batches: activations live in LDS as ONE hi image and ONE lo image (2 x 70 KB) that every layer
+//     overwrites in place — K loop, barrier, epilogue, barrier — which is what lets two boards fit; the residual x never goes through
+//     LDS: every lane keeps the f32 values of its own accumulator elements in registers (128 VGPRs; exact f32, not hi + lo);
+//   * the three products are FUSED per k-step: a wave loads its 4 w_hi and 4 w_lo fragments once and issues 96 MFMAs with them
+//     (48 with one board), so the weight stream is 21 B/clk/CU and the LDS fragment reads are 16 per 96 MFMAs (the bf16 tower: 35 B/clk, 8 per 32);
+//   * the weights of the whole tower are ONE stream in k-step order [conv][tap][k32]{hi 16 KB, lo 16 KB} (sz_nn_tower_split's `w_stream`):
+//     a 2-slot register ring runs one k-step (1,536 matrix-pipe cycles) ahead straight across convolution and tile boundaries;
+//   * position tile j = board row j of both boards (tile_row), so the border-row tiles under the dy = -1 / +1 taps are skipped (8.3 % of the MFMAs);
+//   * every memory instruction sits alone in an MFMA gap, pinned with sched_barrier (as in k_tower16_bf16).
+// WGB = 1 (n_boards <= #CUs: search of a few positions, the tail of a self-play run) runs the same code on one board per workgroup; every output
+// element is accumulated in the same order in both forms (taps, k-steps, hi*hi / lo*hi / hi*lo), so a board's result does not depend on the batch size.
+#include "sz_nn_common.h"
+
+#define NN_MAX_CONVS_SPLIT 129                             // the k-step offset of the weight stream is a 32-bit byte offset: 36 + 72*128 k-steps x 32 KiB
+#define SP_KSTEP_U4 2048                                   // uint4 per k-step of the weight stream: 16 co tiles x 64 lanes hi, then the same for lo
+
+template <int WGB> struct SplitGeom {
+    static constexpr int PITCH = NN_COUT * 2 + NN_PAD16;                      // 544 B per image row (position): conflict-free ds_read_b128
+    static constexpr int IMG = WGB * 64 * PITCH + NN_ZERO16;                  // one image incl. its zero region
+    static constexpr int NJ = 4 * WGB;                                        // position tiles (16) per workgroup
+    static constexpr int TAB = 2 * IMG;                                       // byte offset of the tap address table [9][NJ][64] int
+    static constexpr int LDS_BYTES = 2 * IMG + 9 * NJ * 64 * 4;
+    static constexpr int PITCH_IN = 128 * 2 + NN_PAD16;                       // the stem's input image (128 channels), staged where the lo image lives
+};
+
+// One convolution's K loop on hi/lo operands.  B images: hi at byte offset offH of `lds`, lo at offL (BLO = false: the input is exact in bf16 —
+// the 0/1 planes of the stem — and only w_hi*x + w_lo*x are formed).  Weight stream: global k-steps ks_base .. ks_base + 9*CIN/32 - 1; on entry
+// ring[ks_base & 1] holds k-step ks_base; on exit ring[ks_after & 1]... holds k-step `ks_after` (the next convolution's first, or the stem's of
+// the next tile), fetched under this convolution's last k-step.
+template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */>
+__device__ __forceinline__ void split_kloop(const unsigned char* lds, const int offH, const int offL, const int* addr_tab, const WSrc& wr,
+                                            const uint32_t ks_base, const uint32_t ks_after, const float* __restrict__ bias,
+                                            f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[2][8]) {
+    constexpr int PITCH = CIN * 2 + NN_PAD16;
+    constexpr int KSTEPS = CIN / 32;
+    constexpr int NJ = 4 * WGB, G = WGB;                   // position tiles; groups of 4 tiles per k-step
+    constexpr int NPROD = BLO ? 3 : 2;
+    constexpr bool SKIPROWS = WGB == 2 && NN_ROWSKIP;
+    static_assert(KSTEPS % 2 == 0, "ring slots must be compile-time indices");
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));                         // opaque per call: hipcc otherwise hoists the stem's 72 tap addresses out of the tile loop and spills them
+    const int wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;
+    const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+    {
+        f32x4 binit[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) binit[i] = *(const f32x4*)(bias + (wave * 4 + i) * 16 + 4 * kg);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
+    }
+    auto tap_addr = [&](int tap, int j) -> int {
+        if constexpr (TAB) return addr_tab[(tap * NJ + j) * 64 + lane];
+        else return conv_tap_addr16<PITCH, 9, WGB>(tap, j, p16, kg);
+    };
+    const int lds_base = (int)(uint32_t)(uintptr_t)lds;
+    auto abs_addr = [&](int rel) -> int {
+        int a = lds_base + offH + rel;
+        asm volatile("" : "+v"(a));                        // opaque: the sum stays in the VGPR, the k offset rides in the ds_read immediate
+        return a;
+    };
+    auto LD = [](int addr) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(uint32_t)addr; };
+    int bcurH[NJ], bcurL[BLO ? NJ : 1], bnxt[NJ];
+    bf16x8 bH[2][4], bL[4];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        bnxt[j] = tap_addr(0, j);
+        bcurH[j] = abs_addr(bnxt[j]);
+        if constexpr (BLO) bcurL[j] = bcurH[j] + (offL - offH);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        if (!(SKIPROWS && m == 0)) bH[0][m] = LD(bcurH[m]);                  // tap 0 looks one row up: tile 0 is idle
+    // SK: 1 = position tile 0 idle under this tap (dy = -1), 2 = the last position tile idle (dy = +1)
+    auto tap_body = [&](const int tap, auto skip_tag) {
+        constexpr int SK = decltype(skip_tag)::value;
+        if (tap + 1 < 9) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KSTEPS; kc++) {
+            const int slot = kc & 1;                       // ks_base and tap*KSTEPS are even
+            const uint32_t ks_next = (kc == KSTEPS - 1 && tap == 8) ? ks_after : ks_base + (uint32_t)(tap * KSTEPS + kc + 1);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int buf = (kc * G + g) & 1;
+#pragma unroll
+                for (int prod = 0; prod < NPROD; prod++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][prod == 1 ? 4 + i : i]);
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+                            const bool idle = SKIPROWS && ((SK == 1 && g == 0 && m == 0) || (SK == 2 && g == G - 1 && m == 3));
+                            if (!idle) acc[i][g * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m], 0, 0, 0);
+                            // one memory instruction per MFMA gap
+                            const int q = prod * 16 + i * 4 + m;
+                            if (q < 4) {
+                                // lo fragments of THIS group (used by its third product, 32 gaps on)
+                                if constexpr (BLO && !(ABL & 2)) {
+                                    const bool idl = SKIPROWS && ((SK == 1 && g == 0 && q == 0) || (SK == 2 && g == G - 1 && q == 3));
+                                    if (!idl) bL[q] = LD(bcurL[g * 4 + q] + kc * 64);
+                                }
+                            } else if (q < 8) {
+                                // hi fragments of the NEXT group
+                                const int mm = q - 4;
+                                if (ABL & 2) {
+                                } else if (g + 1 < G) {
+                                    if (!(SKIPROWS && SK == 2 && g + 1 == G - 1 && mm == 3)) bH[buf ^ 1][mm] = LD(bcurH[(g + 1) * 4 + mm] + kc * 64);
+                                } else if (kc + 1 < KSTEPS) {
+                                    if (!(SKIPROWS && SK == 1 && mm == 0)) bH[buf ^ 1][mm] = LD(bcurH[mm] + (kc + 1) * 64);
+                                } else if (tap + 1 < 9) {
+                                    if (!(SKIPROWS && mm == 0 && tap + 1 < 3)) bH[buf ^ 1][mm] = LD(abs_addr(bnxt[mm]));
+                                }
+                            } else if (q < 16 && g == 0) {
+                                // weights of the next k-step (this convolution's, the next convolution's, or the next tile's stem)
+                                const int f = q - 8;
+                                if (!(ABL & 1)) ring[slot ^ 1][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+                            }
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            bcurH[j] = abs_addr(bnxt[j]);
+            if constexpr (BLO) bcurL[j] = bcurH[j] + (offL - offH);
+        }
+    };
+    using SK0 = std::integral_constant<int, 0>;
+    if constexpr (SKIPROWS) {
+        using SK1 = std::integral_constant<int, 1>; using SK2 = std::integral_constant<int, 2>;
+        for (int tap = 0; tap < 3; tap++) tap_body(tap, SK1{});
+        for (int tap = 3; tap < 6; tap++) tap_body(tap, SK0{});
+        for (int tap = 6; tap < 9; tap++) tap_body(tap, SK2{});
+    } else {
+        for (int tap = 0; tap < 9; tap++) tap_body(tap, SK0{});
+    }
+}
+
+// The residual lives in the ACCUMULATION half of the register file between the epilogues (gfx950: 256 arch VGPRs + 256 AGPRs per lane at one wave per
+// SIMD).  Left to itself hipcc kept the accumulators and the K loop's operands in the arch VGPRs and sent most of the 128 residual values to scratch
+// memory: the conv2 epilogue was a chain of scratch_load -> s_waitcnt vmcnt(0), 35k cycles per convolution (in-kernel stamps, profiles/r03b_split_stamps.txt).
+// A value written by v_accvgpr_write has an AGPR-class live range, so it stays there across the K loop.
+__device__ __forceinline__ float to_agpr(float v) { float a; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float from_agpr(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+// ReLU on the f32 bit pattern: a negative float is a negative int32 (v_max_i32: one instruction, no canonicalisation; -0 -> +0)
+__device__ __forceinline__ float relu_f32(float v) { const int i = __builtin_bit_cast(int, v); return __builtin_bit_cast(float, i > 0 ? i : 0); }
+
+// Epilogue of one convolution: every lane turns its own accumulator elements (4 channels of one position per tile) into the hi / lo images.
+//   MODE 0 (stem)  : x = relu(acc)         -> xres, images
+//   MODE 1 (conv1) : t = relu(acc)         -> images            (network.py:70-72)
+//   MODE 2 (conv2) : x = relu(acc + xres)  -> xres, images      (network.py:74-81; the residual is the exact f32 value, kept in registers)
+template <int WGB, int MODE>
+__device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned char* lo_img, const f32x4 (&acc)[4][4 * WGB], float (&xres)[4][4 * WGB][4]) {
+    constexpr int PITCH = NN_COUT * 2 + NN_PAD16;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));                         // opaque per call: the 64 store addresses are not hoisted out of the tile loop (and spilled)
+    const int wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4 * WGB; j++) {
+        const int row = tile_row<WGB>(j, p16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int co = (wave * 4 + i) * 16 + 4 * kg;
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (MODE == 2) v[k] += from_agpr(xres[i][j][k]);
+                v[k] = relu_f32(v[k]);
+                if (MODE != 1) xres[i][j][k] = to_agpr(v[k]);
+            }
+            uint2 h, l;
+            h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]);
+            l.x = pack_bf16x2(v[0] - bf16_lo(h.x), v[1] - bf16_hi(h.x));
+            l.y = pack_bf16x2(v[2] - bf16_lo(h.y), v[3] - bf16_hi(h.y));
+            *(uint2*)(hi_img + row * PITCH + co * 2) = h;
+            *(uint2*)(lo_img + row * PITCH + co * 2) = l;
+        }
+    }
+}
+
+// planes : bit-packed [n_boards][1 KiB] (SZ_NN_IN_BITS) or bf16 NHWC [n_boards][64][128]
+// wstream: the whole tower's weights in k-step order (see the header); bias [n_convs][256] f32 (BatchNorm folded)
+// out    : the tower activation, f32 NHWC [n_boards][64][256]
+// MODE: 0 = shipped; 1 = diagnostic build with s_memtime stamps around the phases of convolutions 7 and 8 of a workgroup's second tile (tools/split_stamps.py; the
+// stamps go to a buffer of their own); 2 / 3 / 4 = stamps + K loop without weight loads / without LDS fragment reads / without both (results garbage)
+#define SPSTAMP(k) do { if (MODE != 0 && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = _t; } } while (0)
+template <int WGB, int MODE>
+__global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restrict__ planes, const uint4* __restrict__ wstream, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int n_boards, int n_blocks, int flags, unsigned long long* __restrict__ stamps) {
+    constexpr int ABL = MODE >= 2 ? MODE - 1 : 0;
+    using GEO = SplitGeom<WGB>;
+    constexpr int NJ = GEO::NJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* imgH = lds;
+    unsigned char* imgL = lds + GEO::IMG;
+    for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) {
+        *(uint4*)(imgH + WGB * 64 * GEO::PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(imgL + WGB * 64 * GEO::PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+    int* addr_tab = (int*)(lds + GEO::TAB);
+    for (int e = threadIdx.x; e < 9 * NJ * 64; e += 256)
+        addr_tab[e] = conv_tap_addr16<GEO::PITCH, 9, WGB>(e / (NJ * 64), (e >> 6) % NJ, e & 15, (e >> 4) & 3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_tiles = (n_boards + WGB - 1) / WGB;
+    const int n_convs = 1 + 2 * n_blocks;
+    const WSrc wr = wfrag_rsrc(wstream);
+    f32x4 acc[4][NJ];
+    float xres[4][NJ][4];                                              // the residual x (exact f32), one value per AGPR
+    uint4 ring[2][8];
+    {   // k-step 0 of the stem
+        const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+#pragma unroll
+        for (int f = 0; f < 8; f++) ring[0][f] = ld_wfrag(wr, (size_t)(f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+    }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int board0 = tile * WGB;
+        // nobody reads the images here: the previous tile ended with epilogue + barrier, its output went out from registers
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(imgL, planes, board0, n_boards);
+        else stage_tile<128, WGB, NN_PAD16>(imgL, planes, board0, n_boards, false);
+        __syncthreads();
+        uint32_t ks = 0;
+        split_kloop<128, WGB, false, false>(lds, GEO::IMG, GEO::IMG, nullptr, wr, ks, n_convs > 1 ? 36u : 0u, bias, acc, ring);
+        ks += 36;
+        __syncthreads();                                               // every wave is done reading the planes
+        split_epilogue<WGB, 0>(imgH, imgL, acc, xres);
+        __syncthreads();
+        for (int c = 1; c < n_convs; c++) {
+            const bool stamp_now = MODE != 0 && (c == 7 || c == 8) && tile == (int)(blockIdx.x + gridDim.x);
+            const int sb = (c & 1) ? 0 : 5;
+            SPSTAMP(sb + 0);
+            split_kloop<256, WGB, true, true, ABL>(lds, 0, GEO::IMG, addr_tab, wr, ks, c + 1 < n_convs ? ks + 72u : 0u, bias + c * NN_COUT, acc, ring);
+            ks += 72;
+            SPSTAMP(sb + 1);
+            __syncthreads();                                           // every wave is done reading the images: they are rewritten in place
+            SPSTAMP(sb + 2);
+            if (c & 1) split_epilogue<WGB, 1>(imgH, imgL, acc, xres);
+            else split_epilogue<WGB, 2>(imgH, imgL, acc, xres);
+            SPSTAMP(sb + 3);
+            __syncthreads();
+            SPSTAMP(sb + 4);
+            if (MODE != 0 && stamp_now && c == 8 && (threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+        }
+        // tower output straight from the registers (exact f32): lane = 4 channels of one position per tile, 64-byte pieces
+        const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int row = tile_row<WGB>(j, p16);
+            if (board0 + (row >> 6) < n_boards) {
+                float* dst = out + ((size_t)board0 * 64 + row) * NN_COUT;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    *(f32x4*)(dst + (wave * 4 + i) * 16 + 4 * kg) = f32x4{from_agpr(xres[i][j][0]), from_agpr(xres[i][j][1]), from_agpr(xres[i][j][2]), from_agpr(xres[i][j][3])};
+            }
+        }
+    }
+}
+
+static unsigned long long* g_split_stamps = nullptr;
+static int g_split_mode = 1;
+
+extern "C" {
+
+// diagnostic: device buffer of 16 u64 per wave (256 workgroups x 4 waves) that receives the phase stamps of the stamped build; NULL = shipped kernel
+int sz_nn_debug_split_stamps(void* dev_buffer, int32_t mode) { g_split_stamps = (unsigned long long*)dev_buffer; g_split_mode = mode; return SZ_OK; }
+
+// Number of uint16 (bf16) elements of the weight stream of a tower with n_blocks BasicBlocks.
+int64_t sz_nn_split_stream_elems(int32_t n_blocks) {
+    if (n_blocks < 0) return SZ_ERR_INVALID;
+    return (int64_t)(36 + 72 * 2 * (int64_t)n_blocks) * SP_KSTEP_U4 * 8;
+}
+
+// Host-side packing of ONE convolution into its place in the weight stream.
+//   w_in  : [256 co][cin_real][3][3] f32 (BatchNorm folded by the caller)
+//   conv  : 0 = stem (cin_real 119, padded to 128: 36 k-steps), c >= 1: the c-th 256-channel convolution (72 k-steps each)
+//   stream: the whole stream (sz_nn_split_stream_elems elements); k-step record = 16 co tiles x 64 lanes x 8 bf16 of w_hi, then of w_lo,
+//           fragment order of sz_nn_pack_weights16: lane l, elem e <- w[co = tile*16 + (l&15)][ci = k32*32 + 8*(l>>4) + e]
+//   w_hi = bf16(w) (round to nearest even), w_lo = bf16(w - w_hi)
+int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t conv, uint16_t* stream) {
+    if (!w_in || !stream || conv < 0 || conv >= NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
+    const int cin_padded = conv == 0 ? 128 : 256;
+    if (cin_real <= 0 || cin_real > cin_padded) return SZ_ERR_INVALID;
+    const int ksteps = cin_padded / 32;
+    const size_t ks0 = conv == 0 ? 0 : 36 + (size_t)(conv - 1) * 72;
+    auto rne = [](float v) -> uint16_t { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    for (int t = 0; t < 9; t++)
+        for (int k = 0; k < ksteps; k++) {
+            uint16_t* rec = stream + (ks0 + (size_t)t * ksteps + k) * SP_KSTEP_U4 * 8;
+            for (int tile = 0; tile < 16; tile++)
+                for (int l = 0; l < 64; l++)
+                    for (int e = 0; e < 8; e++) {
+                        const int co = tile * 16 + (l & 15), ci = k * 32 + 8 * (l >> 4) + e;
+                        const float v = ci < cin_real ? w_in[((size_t)co * cin_real + ci) * 9 + t] : 0.f;
+                        const uint16_t h = rne(v);
+                        const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
+                        rec[((size_t)tile * 64 + l) * 8 + e] = h;
+                        rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = rne(v - hf);
+                    }
+        }
+    return SZ_OK;
+}
+
+// Split-precision tower (k_tower_split): stem + n_blocks BasicBlocks in one persistent launch.
+//   w_stream: device buffer built with sz_nn_pack_split_stream; bias: device [1 + 2*n_blocks][256] f32; out: device [n_boards][64][256] f32 NHWC.
+int sz_nn_tower_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream) {
+    if (!planes || !w_stream || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    static bool attr_flags[NN_MAX_DEVICES] = {};
+    bool& attr_set = attr_flags[current_device_slot()];
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+        attr_set = true;
+    }
+    const int n_cu = device_cus();
+    const bool one = (flags & SZ_NN_SPLIT_WGB1) || (n_boards <= n_cu && !(flags & SZ_NN_SPLIT_WGB2));
+    if (one)
+        hipLaunchKernelGGL((k_tower_split<1, 0>), dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream,
+                           (const uint16_t*)planes, (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, (unsigned long long*)nullptr);
+    else {
+        const int n_tiles = (n_boards + 1) / 2;
+        const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
+#define SPLIT_LAUNCH(M) hipLaunchKernelGGL((k_tower_split<2, M>), grid, dim3(256), SplitGeom<2>::LDS_BYTES, (hipStream_t)stream, (const uint16_t*)planes, (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, g_split_stamps)
+        if (!g_split_stamps) SPLIT_LAUNCH(0);
+        else if (g_split_mode == 2) SPLIT_LAUNCH(2);
+        else if (g_split_mode == 3) SPLIT_LAUNCH(3);
+        else if (g_split_mode == 4) SPLIT_LAUNCH(4);
+        else SPLIT_LAUNCH(1);
+#undef SPLIT_LAUNCH
+    }
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+}  // extern "C"

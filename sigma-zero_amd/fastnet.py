@@ -222,7 +222,7 @@ def planes_nchw_to_nhwc128(planes):
 
 
 class SplitPolicyNet:
-    """policyNN inference at the REFERENCE's precision class on the matrix cores (csrc/sz_nn.hip k_tower16_split).
+    """policyNN inference at the REFERENCE's precision class on the matrix cores (csrc/sz_nn_split.hip k_tower_split).
 
     network.py is fp32 end to end.  FastPolicyNet's bf16 operands keep 8 bits of mantissa (search-level effect measured in
     tests/test_gpu_train_and_precision.py: single visits move).  Here every tower operand is carried as two bf16 numbers, x = hi + lo
@@ -246,18 +246,16 @@ class SplitPolicyNet:
             convs.append(_fold_bn(blk.conv1.weight, blk.bn1))
             convs.append(_fold_bn(blk.conv2.weight, blk.bn2))
         self.n_blocks = len(model.resnet_blocks)
-        self._keep = []
-        hi_ptrs, lo_ptrs, b_ptrs = [], [], []
+        # the whole tower's weights as ONE device buffer in k-step order {w_hi fragments, w_lo fragments} (csrc/sz_nn_split.hip), biases [n_convs, 256]
+        L = N.lib()
+        stream = np.zeros(int(L.sz_nn_split_stream_elems(self.n_blocks)), dtype=np.uint16)
         for k, (w, b) in enumerate(convs):
-            w = w.cpu().float()
-            w_hi = w.to(torch.bfloat16).float()           # round-to-nearest-even, the same rounding the packer applies
-            w_lo = w - w_hi                               # exact in f32; rounded to bf16 by the packer
-            cin_p = 128 if k == 0 else 256
-            th, tl, tb = _pack(w_hi, cin_p, 3, dev, w16=True), _pack(w_lo, cin_p, 3, dev, w16=True), b.to(dev).contiguous()
-            self._keep += [th, tl, tb]
-            hi_ptrs.append(th.data_ptr()); lo_ptrs.append(tl.data_ptr()); b_ptrs.append(tb.data_ptr())
-        n = len(convs)
-        self._wh, self._wl, self._b = (C.c_void_p * n)(*hi_ptrs), (C.c_void_p * n)(*lo_ptrs), (C.c_void_p * n)(*b_ptrs)
+            wk = w.contiguous().cpu().float().numpy()
+            assert wk.shape[0] == 256 and wk.shape[2:] == (3, 3)
+            N.check(L.sz_nn_pack_split_stream(wk.ctypes.data_as(C.c_void_p), wk.shape[1], k, stream.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_stream")
+        self._wstream = torch.from_numpy(stream.view(np.int16)).to(dev)
+        self._bias = torch.stack([b for _, b in convs]).float().contiguous().to(dev)
+        self.force_wgb = 0                                # tests: N.SZ_NN_SPLIT_WGB1 / _WGB2 force one- / two-board workgroups
         # heads as fp32 GEMMs on the NHWC activation (BatchNorm folded in double): [B*64,256] x [256,256] -> ReLU -> x [256,73]; value 256 -> 1 -> MLP
         wp1, bp1 = _fold_bn(model.conv_p1.weight, model.p_norm1)
         self.h_wp1, self.h_bp1 = wp1.view(256, 256).t().contiguous().to(dev), bp1.to(dev)
@@ -287,13 +285,13 @@ class SplitPolicyNet:
         if B > self._cap:
             self._out, self._cap = torch.empty(B, 64, 256, dtype=torch.float32, device=self.device), B
         out = self._out[:B]
-        flags = N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0
+        flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb
         ev = None
         if self.timing is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        N.check(N.lib().sz_nn_tower_split(C.c_void_p(planes.data_ptr()), self._wh, self._wl, self._b, self.n_blocks, C.c_void_p(out.data_ptr()), B, flags,
-                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_split")
+        N.check(N.lib().sz_nn_tower_split(C.c_void_p(planes.data_ptr()), C.c_void_p(self._wstream.data_ptr()), C.c_void_p(self._bias.data_ptr()), self.n_blocks,
+                                          C.c_void_p(out.data_ptr()), B, flags, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_split")
         if ev is not None:
             ev[1].record()
             self.timing.append(ev)

@@ -225,7 +225,7 @@ def test_fused_heads_match_separate_head_kernels():
 
 
 def test_split_precision_network_matches_fp32_policynn():
-    """SplitPolicyNet (k_tower16_split: hi + lo bf16 operands, three MFMAs per product, f32 accumulation, f32 heads) against the fp32 module —
+    """SplitPolicyNet (k_tower_split: hi + lo bf16 operands, three MFMAs per product, f32 accumulation, f32 heads) against the fp32 module —
     the reference's precision class (network.py has no reduced precision anywhere).  Tolerances are ~5x what was measured on MI355X
     (tower activation 9e-6, centred logits 7e-6 relative L2 against fp64; the bf16 tower is at 5e-3)."""
     from sigma_zero_amd.fastnet import SplitPolicyNet
@@ -237,13 +237,21 @@ def test_split_precision_network_matches_fp32_policynn():
                 m.running_mean.normal_(0, 0.05); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.05)
     split = SplitPolicyNet(net)
     g = torch.Generator(device="cuda").manual_seed(11)
-    for B in (1, 37, 300):                                  # fewer boards than CUs, odd counts, more boards than CUs (the persistent tile loop)
+    for B in (1, 37, 300, 1100):                            # fewer boards than CUs (one board per workgroup), odd counts, more boards than CUs (two per workgroup), more tiles than CUs (the persistent tile loop)
         x = (torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
         with torch.no_grad():
             p_ref, v_ref = net(x, inference=False)
             p, v = split(planes_nchw_to_nhwc128(x), inference=False)
             y_ref = net.resnet_blocks(torch.relu(net.norm_layer(net.conv1(x))))
-            y = split.tower(planes_nchw_to_nhwc128(x)).view(B, 8, 8, 256).permute(0, 3, 1, 2)
+            y = split.tower(planes_nchw_to_nhwc128(x)).clone().view(B, 8, 8, 256).permute(0, 3, 1, 2)
+            # a board's activation does not depend on the workgroup form (one or two boards per workgroup) nor on its neighbours: bit for bit
+            split.force_wgb = N.SZ_NN_SPLIT_WGB1
+            y1 = split.tower(planes_nchw_to_nhwc128(x)).clone()
+            split.force_wgb = N.SZ_NN_SPLIT_WGB2
+            y2 = split.tower(planes_nchw_to_nhwc128(x)).clone()
+            y2r = split.tower(planes_nchw_to_nhwc128(x.flip(0))).clone().flip(0)
+            split.force_wgb = 0
+        assert torch.equal(y1, y2) and torch.equal(y2, y2r) and torch.equal(y1.view(B, 8, 8, 256).permute(0, 3, 1, 2), y)
         assert float((y - y_ref).norm() / y_ref.norm()) < 5e-5
         c = lambda t: t - t.mean(1, keepdim=True)
         assert float((c(p) - c(p_ref)).norm() / c(p_ref).norm()) < 5e-5
