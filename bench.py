@@ -18,7 +18,12 @@ One JSON line is printed by rank 0.  Extra objects:
                 rocprofv3 --pmc passes (profiles/pmc_tower_latest.json)
   roofline_tree the hand-written tree kernel (k_search_step), HBM roofline: algorithmic bytes per launch / mean launch duration
   roofline_nn   the whole network forward (tower + heads): 2.915 GFLOP x boards / mean forward duration
+  roofline_split the same workload with the network at the REFERENCE's precision class on the matrix cores (SplitPolicyNet / k_tower_split: hi + lo
+                bf16 operands, 3 MFMAs per product — the configuration that meets north_star's 1e-4 on visit policies): 1 warm-up + 3 timed plies,
+                simulations/s, launch duration of k_tower_split by HIP events, algorithmic AND issued MFMA fraction of the 2.5 PFLOP/s peak (N=1 only)
   parity_config simulations/s of the same boards-per-GPU with the fp32 network the reference uses (bounded sample, N=1 only)
+`--gpus N` with N > 1 outside a launcher (no RANK in the environment) starts N ranks itself (torch.distributed.run on 127.0.0.1) before any GPU call,
+as the reference spawns its own self-play workers (train_RL.py:215-227); under a launcher WORLD_SIZE must equal --gpus.
   cpu_baseline  the oracle (reference algorithm restated on the CPU: one leaf per step, per-game pointer tree,
                 batch-1 fp32 forward on the host cores) on BASELINE.json configs[0], timed on rank 0 over a bounded sample
 """
@@ -108,47 +113,118 @@ def cpu_baseline(budget_s=15.0):
 
 
 def parity_config_sample(dev, B, chess960, n_searches=40):
-    """Throughput at the REFERENCE's precision (network.py is fp32 end to end; no mixed precision anywhere), same boards-per-GPU, one whole
-    ply at a small search budget (the cost of a simulation does not depend on the budget: trees stay shallow).  Two legs:
-      value / torch_fp32  fp32 policyNN through torch/MIOpen on fp32 NCHW planes — the reference's arithmetic itself;
-      mfma_split          the same weights on the matrix cores with every operand split into two bf16 numbers and three MFMAs per product
-                          (SplitPolicyNet / k_tower16_split, f32 accumulation, f32 heads): reproduces the fp32 network's SEARCH results
-                          (tests: 64/64 boards identical visit counts, the configs[0] game ply for ply).
-    Bounded samples next to the bf16 headline, not the headline."""
+    """Throughput at the REFERENCE's own arithmetic (network.py is fp32 end to end; no mixed precision anywhere), same boards-per-GPU: fp32 policyNN
+    through torch/MIOpen on fp32 NCHW planes, one whole ply at a small search budget (the cost of a simulation does not depend on the budget: trees
+    stay shallow).  A bounded sample next to the bf16 headline, not the headline; the matrix-core path of the same precision class is `roofline_split`."""
+    import sigma_zero_amd as sz
+    from sigma_zero_amd.selfplay import SelfPlayEngine
+    torch.manual_seed(0)
+    net = sz.policyNN({}).eval().to(dev)
+    eng = SelfPlayEngine(net, {"C": 2, "num_searches": n_searches}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype=torch.float32)
+    eng.new_games([-1] * B)
+    with torch.no_grad():
+        eng.begin()
+        eng.evaluate(eng.planes)                           # warm-up forward (MIOpen algorithm search) outside the timed region
+        torch.cuda.synchronize(dev)
+        st0 = eng.stats()
+        t0 = time.perf_counter()
+        eng.search()
+        eng.play(np.random.RandomState(7).random_sample(B))
+        eng.fetch_ply()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    st1 = eng.check_errors()
+    eng.close()
+    sims = st1["simulations"] - st0["simulations"]
+    return {"value": sims / dt, "unit": "simulations/s", "dtype": "f32", "network": "policyNN fp32 (torch / MIOpen), NCHW fp32 planes",
+            "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, n_searches, sims, dt),
+            "search_level_gap_of_bf16": "profiles/r02a_bf16_vs_fp32_search_S{100,800}.json (tests/test_gpu_train_and_precision.py)"}
+
+
+def split_tower_flops(B):
+    """(algorithmic, issued) FLOP of one k_tower_split launch over B boards.  Algorithmic: the standard convolution FLOP of the tower (9 taps x 64
+    positions, padding included: 2.915 GFLOP per board minus the heads).  Issued: what its MFMAs execute — three products per 256-channel convolution,
+    two for the stem (0/1 planes have no lo part; 128 padded input channels), 66 of 72 (tap, board-row) tiles (the all-zero border rows are skipped)."""
+    alg = 2.0 * B * 64 * 256 * 9 * (119 + 38 * 256)
+    mfma_per_wave_tile = 66 * 4 * 2 * 4 + 38 * (66 * 8 * 3 * 4)          # (tap-tiles) x k32-steps x products x channel tiles
+    issued = ((B + 1) // 2) * 4 * mfma_per_wave_tile * (2.0 * 16 * 16 * 32)
+    return alg, issued
+
+
+def split_sample(dev, B, S, chess960, plies=3, warmup=1):
+    """The headline workload with the network at the reference's precision class on the matrix cores: `warmup` + `plies` full plies of B boards x S
+    searches (finished games restart), timed like the headline; the tower launch is sampled with HIP events on the launch stream."""
+    import random
     import sigma_zero_amd as sz
     from sigma_zero_amd.selfplay import SelfPlayEngine
     from sigma_zero_amd.fastnet import SplitPolicyNet
     torch.manual_seed(0)
-    net = sz.policyNN({}).eval().to(dev)
+    model = SplitPolicyNet(sz.policyNN({}).eval().to(dev), device=dev)
+    eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype="bits128")
+    prng, rng = random.Random(0), np.random.RandomState(99)
+    eng.new_games([prng.randrange(960) if chess960 else -1 for _ in range(B)])
+    events = []
 
-    def one(model, planes_dtype, S):
-        eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype=planes_dtype)
-        eng.new_games([-1] * B)
-        with torch.no_grad():
-            eng.begin()
-            eng.evaluate(eng.planes)                           # warm-up forward (MIOpen algorithm search) outside the timed region
-            torch.cuda.synchronize(dev)
-            st0 = eng.stats()
-            t0 = time.perf_counter()
-            eng.search()
-            eng.play(np.random.RandomState(7).random_sample(B))
-            eng.fetch_ply()
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-        st1 = eng.check_errors()
-        eng.close()
-        return st1["simulations"] - st0["simulations"], dt
+    @torch.no_grad()
+    def ply(timed):
+        eng.begin()
+        for it in range(S):
+            model.timing = events if (timed and it % 50 == 25) else None
+            policy, value = model(eng.planes, inference=True)
+            eng.step(policy, value.reshape(-1))
+        model.timing = None
+        eng.play(rng.random_sample(B))
+        rec = eng.fetch_ply()
+        over = rec["game_over"].astype(bool) & rec["active"].astype(bool)
+        if over.any():
+            eng.new_games([prng.randrange(960) if chess960 else -1 for _ in range(B)], active=over.astype(np.uint8))
 
-    sims, dt = one(net, torch.float32, n_searches)
-    out = {"value": sims / dt, "unit": "simulations/s", "dtype": "f32", "network": "policyNN fp32 (torch / MIOpen), NCHW fp32 planes",
-           "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, n_searches, sims, dt),
-           "search_level_gap_of_bf16": "profiles/r02a_bf16_vs_fp32_search_S{100,800}.json (tests/test_gpu_train_and_precision.py)"}
-    S2 = 4 * n_searches
-    sims2, dt2 = one(SplitPolicyNet(net, device=dev), "bits128", S2)
-    out["mfma_split"] = {"value": sims2 / dt2, "unit": "simulations/s", "dtype": "bf16x2 operands (hi + lo), 3 MFMAs per product, f32 accumulate, f32 heads",
-                         "network": "SplitPolicyNet: k_tower16_split + fp32 GEMM heads",
-                         "sample": "%d boards x num_searches=%d, one ply, %d simulations in %.2f s" % (B, S2, sims2, dt2)}
-    return out
+    for _ in range(warmup):
+        ply(False)
+    st0 = eng.check_errors()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(plies):
+        ply(True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st1 = eng.check_errors()
+    eng.close()
+    sims = st1["simulations"] - st0["simulations"]
+    ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    alg, issued = split_tower_flops(B)
+    atf, itf = alg / (ms * 1e-3) / 1e12, issued / (ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    try:
+        import sigma_zero_amd.build as _b
+        with open(os.path.join(ROOT, "profiles", "pmc_split_latest.json")) as f:
+            traffic_src = json.load(f)
+        if B == 4096 and traffic_src.get("source_hash") == _b.source_hash("split"):
+            traffic = traffic_src["hbm_bytes_per_launch"]
+        else:
+            traffic_src = {"source": traffic_src.get("source"), "stale": "other batch size, or sz_nn_split.hip changed since these counters were collected"}
+    except Exception:
+        pass
+    return {"kernel": "k_tower_split<%d> (persistent: stem + 19 BasicBlocks per launch on hi + lo bf16 operands, 3 MFMAs per product, f32 accumulate; f32 heads)" % (2 if B > 256 else 1),
+            "bound": "mfma", "achieved": atf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": atf / MFMA_BF16_PEAK_TFLOPS,
+            "issued": itf, "issued_frac": itf / MFMA_BF16_PEAK_TFLOPS, "launch_ms": ms, "sampled_launches": len(events),
+            "algorithmic_flop_per_launch": alg, "issued_mfma_flop_per_launch": issued, "traffic": traffic, "traffic_source": traffic_src,
+            "value": sims / dt, "value_unit": "simulations/s", "dtype": "bf16x2", "plies": plies, "warmup": warmup, "ms_per_step": 1e3 * dt / plies,
+            "sim_count_ok": bool(sims == B * S * plies),
+            "config": {"workload": "selfplay_%dboards_%dsearches" % (B, S), "network": "SplitPolicyNet (reference precision class: identical visit counts to the fp32 network in tests)"}}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) before anything in this process has touched the GPU, relay their output
+    (rank 0 prints the JSON line) and return their exit code.  The reference spawns its own workers the same way (train_RL.py:215-227)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -168,12 +244,20 @@ def main():
     ap.add_argument("--edges-per-board", type=int, default=0, help="child slots per board (0 = engine default: worst case when it fits in half of the free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-config", action="store_true", help="skip the fp32-network sample (`parity_config`)")
+    ap.add_argument("--no-split", action="store_true", help="skip the reference-precision run on the matrix cores (`roofline_split`)")
+    ap.add_argument("--split-plies", type=int, default=3, help="timed plies of the `roofline_split` run (after one warm-up ply)")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))        # nothing above this line has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; the line would report the wrong job size" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the search path has no CPU fallback")
     if a.dist_backend == "gloo":
@@ -262,12 +346,13 @@ def main():
 
     sims = st1["simulations"] - st0["simulations"]
     exps = st1["expansions"] - st0["expansions"]
-    # every board ran a full search in every timed ply (finished games are refilled, the counters survive the refill)
-    assert sims == B * S * a.steps, "simulation counter %d != boards x searches x steps = %d" % (sims, B * S * a.steps)
     sum_depth = st1["sum_depth"] - st0["sum_depth"]
     sum_k = st1["sum_children"] - st0["sum_children"]
     from sigma_zero_amd.train_rl import aggregate_throughput
-    (total_sims, total_exps), dt_max = aggregate_throughput([sims, exps], dt, device="cpu" if a.dist_backend == "gloo" else dev)
+    # every board ran a full search in every timed ply (finished games are refilled, the counters survive the refill); reported, not asserted:
+    # a rank-local assert in front of the collectives would leave the other ranks hanging in them
+    bad = 0.0 if sims == B * S * a.steps else 1.0
+    (total_sims, total_exps, bad_ranks), dt_max = aggregate_throughput([sims, exps, bad], dt, device="cpu" if a.dist_backend == "gloo" else dev)
 
     if rank == 0:
         out = {
@@ -281,6 +366,7 @@ def main():
             "expansions_per_s": total_exps / dt_max,
             "mean_leaf_depth": sum_depth / max(sims, 1), "mean_children": sum_k / max(exps, 1),
             "max_edges_used": st1["max_edges_used"],
+            "sim_count_ok": bad_ranks == 0,     # simulations == boards x searches x steps on every rank
         }
         if use_events and ev_tree:
             tree_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_tree]))
@@ -296,6 +382,10 @@ def main():
                 with open(os.path.join(ROOT, "profiles", "pmc_tree_latest.json")) as f:
                     tree_src = json.load(f)
                 tree_traffic = tree_src["hbm_bytes_per_launch"] if (fast and B == 4096 and tree_src.get("planes") == a.planes) else None
+                import sigma_zero_amd.build as _b
+                if tree_traffic is not None and tree_src.get("source_hash") != _b.source_hash("tree"):
+                    tree_traffic = None
+                    tree_src = dict(tree_src, stale="sz_engine.hip / sz_chess.h changed since these counters were collected: run tools/profile_round.sh")
             except Exception:
                 pass
             tree_roof = {"kernel": "k_search_step", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -321,23 +411,39 @@ def main():
                     with open(os.path.join(ROOT, "profiles", "pmc_tower_latest.json" if whole else "pmc_conv_latest.json")) as f:
                         traffic_src = json.load(f)
                     traffic = traffic_src["hbm_bytes_per_launch"] if ((fused or whole) and not split and B == 4096 and (not whole or traffic_src.get("planes") == a.planes)) else None
+                    # the counters belong to the kernel sources they were collected from: a record from other sources is not this binary's traffic
+                    import sigma_zero_amd.build as _b
+                    if traffic is not None and whole and traffic_src.get("source_hash") != _b.source_hash("tower"):
+                        traffic = None
+                        traffic_src = dict(traffic_src, stale="the kernel sources changed since these counters were collected (source_hash %s, now %s): run tools/profile_round.sh"
+                                           % (traffic_src.get("source_hash"), _b.source_hash("tower")))
                 except Exception:
                     pass
-                out["roofline"] = {"kernel": "k_tower16_split (persistent, hi+lo bf16 operands: 3 MFMAs per algorithmic product)" if split
+                out["roofline"] = {"kernel": "k_tower_split (persistent, hi+lo bf16 operands: 3 MFMAs per algorithmic product)" if split
                                    else "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole
                                    else "k_block16_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU, 16x16x32 MFMA)" if fused
                                    else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
                                    "launch_ms": conv_ms, "algorithmic_flop_per_launch": conv_flop, "sampled_launches": len(conv_events),
                                    "traffic": traffic, "traffic_source": traffic_src}
+                if split:
+                    _, issued = split_tower_flops(B)
+                    out["roofline"]["issued"] = issued / (conv_ms * 1e-3) / 1e12
+                    out["roofline"]["issued_frac"] = out["roofline"]["issued"] / MFMA_BF16_PEAK_TFLOPS
                 out["roofline_tree"] = tree_roof
                 out["roofline_nn"] = nn_roof
             else:
                 out["roofline"] = tree_roof
                 out["roofline_nn"] = nn_roof
         # the two side measurements must never cost the headline line: a failure is reported in their place
-        if not a.no_parity_config and world == 1 and fast:
+        if world == 1 and fast:
             eng.close()
+        if not a.no_split and world == 1 and fast and not split:
+            try:
+                out["roofline_split"] = split_sample(dev, B, S, a.chess960, plies=a.split_plies)
+            except Exception as ex:                     # noqa: BLE001
+                out["roofline_split"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
+        if not a.no_parity_config and world == 1 and fast:
             try:
                 out["parity_config"] = parity_config_sample(dev, B, a.chess960)
             except Exception as ex:                     # noqa: BLE001

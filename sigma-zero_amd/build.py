@@ -44,10 +44,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def source_hash():
-    """sha1 over the kernel sources and headers: ties a profile record to the code it was taken from (bench.py `traffic`)"""
+HASH_GROUPS = {"tower": ["sz_nn.hip", "sz_nn_common.h"], "split": ["sz_nn_split.hip", "sz_nn_common.h"], "tree": ["sz_engine.hip", "sz_chess.h"]}
+
+
+def source_hash(group="all"):
+    """sha1 over kernel sources: ties a profile record to the code it was taken from (bench.py `traffic`).  group: "tower" (k_tower16_bf16),
+    "split" (k_tower_split), "tree" (k_search_step) or "all"."""
+    files = sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS) if group == "all" else [os.path.join(CSRC, f) for f in HASH_GROUPS[group]]
     h = hashlib.sha1()
-    for p in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+    for p in files:
         with open(p, "rb") as f:
             h.update(os.path.basename(p).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
