@@ -210,7 +210,19 @@ int sz_nn_tower_split(const void* planes, const void* w_stream, const float* bia
 /* host: number of bf16 elements of the weight stream; one convolution (conv 0 = stem, cin_real 119; conv c >= 1: the c-th 256-channel 3x3
  * convolution in forward order) from the torch weight [256,cin_real,3,3] f32 into its place in the stream */
 int64_t sz_nn_split_stream_elems(int32_t n_blocks);
-int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t conv, uint16_t* stream);
+int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t ksize /* 3; 1 for conv_p1 */, int32_t conv, uint16_t* stream);
+/* The WHOLE network (network.py:176-192) at that precision class in two launches: the tower above with both heads fused onto each tile while it is still in
+ * LDS — conv_p1 (packed into the stream as convolution 1 + 2*n_blocks with ksize 1, its folded bias as the last row of `bias`) -> ReLU -> conv_p2
+ * (w_p2_packed from sz_nn_pack_split_head, 8*2*5*64*8 bf16 elements; b_p2 [73]) -> softmax over the 4672 logits, all on hi + lo operands; conv_v1 (wv [256],
+ * bv: v_norm folded) in f32 — then the value MLP (sz_nn_value_mlp).  probs [n_boards,4672] f32 in the reference's flatten order (logits if !do_softmax),
+ * value [n_boards], v1_scratch [n_boards*64] f32, tower_out: NULL or [n_boards,64,256] f32.  Every reduction runs in an order that does not depend on the
+ * batch size or on the neighbours of a board: a position's policy and value are the same bit for bit at batch 1 and at batch 4096. */
+int sz_nn_forward_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, const void* w_p2_packed, const float* b_p2,
+                        const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value,
+                        float* v1_scratch, float* tower_out, int32_t n_boards, int32_t do_softmax, int32_t flags, void* stream);
+int sz_nn_pack_split_head(const float* w_in /* conv_p2.weight [73,256] */, uint16_t* out);
+/* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
+int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */
 int sz_nn_debug_split_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
 /* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records

@@ -1282,6 +1282,28 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
+// Value MLP alone (network.py:162-172): v1 [n_boards][64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards].  f32 throughout;
+// the second launch of sz_nn_heads_bf16 and of sz_nn_forward_split.
+int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream) {
+    if (!v1 || !fc1_w_t || !fc1_b || !fc2_w || !value || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    const size_t lds_v = (64 * 256 + 16 * 64) * sizeof(float);
+    static bool attr_flags[NN_MAX_DEVICES] = {};
+    bool& attr_set = attr_flags[current_device_slot()];
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        HIPCHK(hipFuncSetAttribute((const void*)k_value_head<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+        attr_set = true;
+    }
+    if (n_boards > 2048)
+        hipLaunchKernelGGL(k_value_head<4>, dim3((n_boards + 15) / 16), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)nullptr, (const float*)nullptr, 0.f, fc1_w_t, fc1_b, fc2_w, fc2_b,
+                           value, n_boards, v1);
+    else
+        hipLaunchKernelGGL(k_value_head<1>, dim3((n_boards + 3) / 4), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)nullptr, (const float*)nullptr, 0.f, fc1_w_t, fc1_b, fc2_w, fc2_b,
+                           value, n_boards, v1);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
 // host: conv_p2.weight [73][256] f32 -> [8 k32-steps][5 co tiles][64 lanes][8] bf16 (channels 73..79 zero)
 int sz_nn_pack_head16(const float* w_in, uint16_t* out) {
     if (!w_in || !out) return SZ_ERR_INVALID;

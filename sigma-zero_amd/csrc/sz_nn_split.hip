@@ -30,7 +30,8 @@ template <int WGB> struct SplitGeom {
     static constexpr int IMG = WGB * 64 * PITCH + NN_ZERO16;                  // one image incl. its zero region
     static constexpr int NJ = 4 * WGB;                                        // position tiles (16) per workgroup
     static constexpr int TAB = 2 * IMG;                                       // byte offset of the tap address table [9][NJ][64] int
-    static constexpr int LDS_BYTES = 2 * IMG + 9 * NJ * 64 * 4;
+    static constexpr int SCR = 2 * IMG + 9 * NJ * 64 * 4;                     // byte offset of the heads' scratch: [WGB][64] position sums, [4 waves][2] maxima
+    static constexpr int LDS_BYTES = SCR + 1024;
     static constexpr int PITCH_IN = 128 * 2 + NN_PAD16;                       // the stem's input image (128 channels), staged where the lo image lives
 };
 
@@ -38,7 +39,8 @@ template <int WGB> struct SplitGeom {
 // the 0/1 planes of the stem — and only w_hi*x + w_lo*x are formed).  Weight stream: global k-steps ks_base .. ks_base + 9*CIN/32 - 1; on entry
 // ring[ks_base & 1] holds k-step ks_base; on exit ring[ks_after & 1]... holds k-step `ks_after` (the next convolution's first, or the stem's of
 // the next tile), fetched under this convolution's last k-step.
-template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */>
+template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */,
+          int NTAPS = 9 /* 1: a 1x1 convolution on the same images (conv_p1 of the fused heads) */>
 __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int offH, const int offL, const int* addr_tab, const WSrc& wr,
                                             const uint32_t ks_base, const uint32_t ks_after, const float* __restrict__ bias,
                                             f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[2][8]) {
@@ -46,7 +48,8 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
     constexpr int KSTEPS = CIN / 32;
     constexpr int NJ = 4 * WGB, G = WGB;                   // position tiles; groups of 4 tiles per k-step
     constexpr int NPROD = BLO ? 3 : 2;
-    constexpr bool SKIPROWS = WGB == 2 && NN_ROWSKIP;
+    constexpr bool SKIPROWS = WGB == 2 && NN_ROWSKIP && NTAPS == 9;
+    static_assert(NTAPS == 9 || NTAPS == 1, "3x3 or 1x1");
     static_assert(KSTEPS % 2 == 0, "ring slots must be compile-time indices");
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));                         // opaque per call: hipcc otherwise hoists the stem's 72 tap addresses out of the tile loop and spills them
@@ -63,8 +66,8 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
             for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
     }
     auto tap_addr = [&](int tap, int j) -> int {
-        if constexpr (TAB) return addr_tab[(tap * NJ + j) * 64 + lane];
-        else return conv_tap_addr16<PITCH, 9, WGB>(tap, j, p16, kg);
+        if constexpr (TAB) return addr_tab[((NTAPS == 1 ? 4 : tap) * NJ + j) * 64 + lane];      // 1x1: the centre tap of the 3x3 table
+        else return conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
     };
     const int lds_base = (int)(uint32_t)(uintptr_t)lds;
     auto abs_addr = [&](int rel) -> int {
@@ -87,14 +90,14 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
     // SK: 1 = position tile 0 idle under this tap (dy = -1), 2 = the last position tile idle (dy = +1)
     auto tap_body = [&](const int tap, auto skip_tag) {
         constexpr int SK = decltype(skip_tag)::value;
-        if (tap + 1 < 9) {
+        if (tap + 1 < NTAPS) {
 #pragma unroll
             for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
         }
 #pragma unroll
         for (int kc = 0; kc < KSTEPS; kc++) {
             const int slot = kc & 1;                       // ks_base and tap*KSTEPS are even
-            const uint32_t ks_next = (kc == KSTEPS - 1 && tap == 8) ? ks_after : ks_base + (uint32_t)(tap * KSTEPS + kc + 1);
+            const uint32_t ks_next = (kc == KSTEPS - 1 && tap == NTAPS - 1) ? ks_after : ks_base + (uint32_t)(tap * KSTEPS + kc + 1);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int buf = (kc * G + g) & 1;
@@ -123,7 +126,7 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                                     if (!(SKIPROWS && SK == 2 && g + 1 == G - 1 && mm == 3)) bH[buf ^ 1][mm] = LD(bcurH[(g + 1) * 4 + mm] + kc * 64);
                                 } else if (kc + 1 < KSTEPS) {
                                     if (!(SKIPROWS && SK == 1 && mm == 0)) bH[buf ^ 1][mm] = LD(bcurH[mm] + (kc + 1) * 64);
-                                } else if (tap + 1 < 9) {
+                                } else if (tap + 1 < NTAPS) {
                                     if (!(SKIPROWS && mm == 0 && tap + 1 < 3)) bH[buf ^ 1][mm] = LD(abs_addr(bnxt[mm]));
                                 }
                             } else if (q < 16 && g == 0) {
@@ -138,10 +141,12 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                 }
             }
         }
+        if (NTAPS > 1) {
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            bcurH[j] = abs_addr(bnxt[j]);
-            if constexpr (BLO) bcurL[j] = bcurH[j] + (offL - offH);
+            for (int j = 0; j < NJ; j++) {
+                bcurH[j] = abs_addr(bnxt[j]);
+                if constexpr (BLO) bcurL[j] = bcurH[j] + (offL - offH);
+            }
         }
     };
     using SK0 = std::integral_constant<int, 0>;
@@ -151,7 +156,7 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
         for (int tap = 3; tap < 6; tap++) tap_body(tap, SK0{});
         for (int tap = 6; tap < 9; tap++) tap_body(tap, SK2{});
     } else {
-        for (int tap = 0; tap < 9; tap++) tap_body(tap, SK0{});
+        for (int tap = 0; tap < NTAPS; tap++) tap_body(tap, SK0{});
     }
 }
 
@@ -198,15 +203,161 @@ __device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned c
     }
 }
 
+// ---- fused heads (network.py:141-174) on the tile while x is still in LDS as hi / lo images -------------------------------------------------
+struct SplitHeadsParams {
+    const uint4* w_p2;       // conv_p2 (73 -> 80 channels), sz_nn_pack_split_head: [8 k32-steps]{hi: 5 co tiles x 64 lanes, lo: the same} uint4
+    const float* b_p2;       // [73]
+    const float* wv;         // [256] conv_v1 with v_norm folded
+    float bv;
+    float* probs;            // [n_boards][4672] f32, the reference's flatten order plane*64 + position
+    float* v1_out;           // [n_boards][64] relu(bn(conv_v1(x))) (the 64 -> 256 -> 1 MLP is k_value_head)
+    int do_softmax;
+};
+
+// value : conv_v1 (256 -> 1) + ReLU per position, one f32 fma chain over the channels in ascending order
+// policy: t = relu(bn(conv_p1(x))) on the tower's K loop (1x1) -> hi / lo images over x -> conv_p2 (three products again) + bias -> softmax over the
+//         board's 4672 logits.
+// Every sum runs in an order that does not depend on the workgroup form: per position over (channel tile, register) in the lane, the two shuffles over
+// the lane's channel quarter, then the 64 positions of the board one after the other from LDS.  So a board's probabilities are the same bit for bit
+// whether it ran alone in a workgroup, beside another board, at batch 1 or 4096 (the self-play records of a game do not depend on the batch it ran in).
+template <int WGB>
+__device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* addr_tab, const WSrc& wr, const uint32_t ks_p1, const float* __restrict__ bias_p1,
+                                                 const SplitHeadsParams& hp, f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[2][8], float (&xres)[4][4 * WGB][4],
+                                                 const int board0, const int n_boards) {
+    using GEO = SplitGeom<WGB>;
+    constexpr int NJ = GEO::NJ, NT = WGB, PITCH = GEO::PITCH;          // NT: position tiles per wave in conv_p2
+    unsigned char* imgH = lds;
+    unsigned char* imgL = lds + GEO::IMG;
+    float* psum = (float*)(lds + GEO::SCR);                            // [WGB][64]
+    float* red = psum + WGB * 64;                                      // [4 waves][2 boards]
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = threadIdx.x >> 6, p16 = lane & 15, kg = lane >> 4;
+    {   // value conv: one image row (board*64 + position) per thread
+        const int row = wave * 64 + lane;
+        if (row < WGB * 64) {
+            const unsigned char* ph = imgH + row * PITCH;
+            const unsigned char* pl = imgL + row * PITCH;
+            float sv = 0.f;
+#pragma unroll 4
+            for (int c8 = 0; c8 < 32; c8++) {
+                const uint4 h = *(const uint4*)(ph + c8 * 16), l = *(const uint4*)(pl + c8 * 16);
+                const float4 w0 = ((const float4*)hp.wv)[c8 * 2], w1 = ((const float4*)hp.wv)[c8 * 2 + 1];
+                sv = __builtin_fmaf(w0.x, bf16_lo(h.x) + bf16_lo(l.x), sv); sv = __builtin_fmaf(w0.y, bf16_hi(h.x) + bf16_hi(l.x), sv);
+                sv = __builtin_fmaf(w0.z, bf16_lo(h.y) + bf16_lo(l.y), sv); sv = __builtin_fmaf(w0.w, bf16_hi(h.y) + bf16_hi(l.y), sv);
+                sv = __builtin_fmaf(w1.x, bf16_lo(h.z) + bf16_lo(l.z), sv); sv = __builtin_fmaf(w1.y, bf16_hi(h.z) + bf16_hi(l.z), sv);
+                sv = __builtin_fmaf(w1.z, bf16_lo(h.w) + bf16_lo(l.w), sv); sv = __builtin_fmaf(w1.w, bf16_hi(h.w) + bf16_hi(l.w), sv);
+            }
+            const int board = board0 + (row >> 6);
+            if (board < n_boards) hp.v1_out[(size_t)board * 64 + (row & 63)] = fmaxf(sv + hp.bv, 0.f);
+        }
+    }
+    split_kloop<256, WGB, true, true, 0, 1>(lds, 0, GEO::IMG, addr_tab, wr, ks_p1, 0u, bias_p1, acc, ring);     // fetches the next tile's first stem k-step on its way out
+    __syncthreads();                                                   // every wave is done reading x
+    split_epilogue<WGB, 1>(imgH, imgL, acc, xres);                     // t over x
+    __syncthreads();
+    // conv_p2: wave w owns position tiles w*NT .. w*NT + NT - 1, all 5 channel tiles; K = 256
+    f32x4 pa[5][NT];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) pa[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int baddr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) baddr[t] = addr_tab[(4 * NJ + wave * NT + t) * 64 + lane];       // centre tap: the lane's own row of tile wave*NT + t, + 16*kg
+#pragma unroll 2
+    for (int kc = 0; kc < 8; kc++) {
+        bf16x8 ah[5], al[5], bh[NT], bl[NT];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            ah[i] = __builtin_bit_cast(bf16x8, hp.w_p2[(size_t)(kc * 10 + i) * 64 + lane]);
+            al[i] = __builtin_bit_cast(bf16x8, hp.w_p2[(size_t)(kc * 10 + 5 + i) * 64 + lane]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) { bh[t] = *(const bf16x8*)(imgH + baddr[t] + kc * 64); bl[t] = *(const bf16x8*)(imgL + baddr[t] + kc * 64); }
+#pragma unroll
+        for (int prod = 0; prod < 3; prod++)
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    pa[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(prod == 1 ? al[i] : ah[i], prod == 2 ? bl[t] : bh[t], pa[i][t], 0, 0, 0);
+    }
+    __syncthreads();                                                   // every wave is done reading t: the next tile may stage its planes
+    // lane holds the logits of positions tile_row(wave*NT + t, p16), channels i*16 + 4*kg + r
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int co = i * 16 + 4 * kg + r;
+            const float bb = co < 73 ? hp.b_p2[co] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                pa[i][t][r] += bb;
+                if (co < 73) mx = fmaxf(mx, pa[i][t][r]);
+            }
+        }
+    const int lboard = WGB == 2 ? (p16 >> 3) : 0;                      // the lane's board inside the workgroup (tile_row: lanes 8..15 of a tile are board 1)
+    float inv = 1.0f;
+    if (hp.do_softmax) {                                               // uniform across the workgroup
+        // maximum over the board (exact in any order): lanes of the same board, then the four waves
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        if (WGB == 1) mx = fmaxf(mx, __shfl_xor(mx, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if ((lane & (WGB == 2 ? 0x37 : 0x3F)) == 0) red[wave * 2 + lboard] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0 + lboard], red[2 + lboard]), fmaxf(red[4 + lboard], red[6 + lboard]));
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int co = i * 16 + 4 * kg + r;
+                    const float e = co < 73 ? __expf(pa[i][t][r] - mx) : 0.f;
+                    pa[i][t][r] = e;
+                    ps += e;
+                }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            const int row = tile_row<WGB>(wave * NT + t, p16);
+            if (kg == 0) psum[row] = ps;                               // row = board*64 + position
+        }
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll 8
+        for (int p = 0; p < 64; p++) tot += psum[lboard * 64 + p];
+        inv = 1.0f / tot;
+    }
+    if (board0 + lboard < n_boards) {
+        float* pb = hp.probs + (size_t)(board0 + lboard) * 4672;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int pos = tile_row<WGB>(wave * NT + t, p16) & 63;
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int co = i * 16 + 4 * kg + r;
+                    if (co < 73) pb[co * 64 + pos] = pa[i][t][r] * inv;
+                }
+        }
+    }
+}
+
 // planes : bit-packed [n_boards][1 KiB] (SZ_NN_IN_BITS) or bf16 NHWC [n_boards][64][128]
 // wstream: the whole tower's weights in k-step order (see the header); bias [n_convs][256] f32 (BatchNorm folded)
 // out    : the tower activation, f32 NHWC [n_boards][64][256]
 // MODE: 0 = shipped; 1 = diagnostic build with s_memtime stamps around the phases of convolutions 7 and 8 of a workgroup's second tile (tools/split_stamps.py; the
 // stamps go to a buffer of their own); 2 / 3 / 4 = stamps + K loop without weight loads / without LDS fragment reads / without both (results garbage)
 #define SPSTAMP(k) do { if (MODE != 0 && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = _t; } } while (0)
-template <int WGB, int MODE>
+// HEADS: both heads run on the tile at the end (split_heads_tail; hp.probs / hp.v1_out instead of `out`, which may then be NULL)
+template <int WGB, int MODE, bool HEADS>
 __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restrict__ planes, const uint4* __restrict__ wstream, const float* __restrict__ bias,
-                                                         float* __restrict__ out, int n_boards, int n_blocks, int flags, unsigned long long* __restrict__ stamps) {
+                                                         float* __restrict__ out, int n_boards, int n_blocks, int flags, unsigned long long* __restrict__ stamps,
+                                                         const SplitHeadsParams hp) {
     constexpr int ABL = MODE >= 2 ? MODE - 1 : 0;
     using GEO = SplitGeom<WGB>;
     constexpr int NJ = GEO::NJ;
@@ -239,7 +390,9 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
         else stage_tile<128, WGB, NN_PAD16>(imgL, planes, board0, n_boards, false);
         __syncthreads();
         uint32_t ks = 0;
-        split_kloop<128, WGB, false, false>(lds, GEO::IMG, GEO::IMG, nullptr, wr, ks, n_convs > 1 ? 36u : 0u, bias, acc, ring);
+        const uint32_t ks_p1 = 36u + 72u * (uint32_t)(n_convs - 1);    // conv_p1's 8 k-steps follow the tower's in the stream
+        const uint32_t ks_end = HEADS ? ks_p1 : 0u;                    // what the tower's last convolution prefetches: conv_p1, or the next tile's stem
+        split_kloop<128, WGB, false, false>(lds, GEO::IMG, GEO::IMG, nullptr, wr, ks, n_convs > 1 ? 36u : ks_end, bias, acc, ring);
         ks += 36;
         __syncthreads();                                               // every wave is done reading the planes
         split_epilogue<WGB, 0>(imgH, imgL, acc, xres);
@@ -248,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
             const bool stamp_now = MODE != 0 && (c == 7 || c == 8) && tile == (int)(blockIdx.x + gridDim.x);
             const int sb = (c & 1) ? 0 : 5;
             SPSTAMP(sb + 0);
-            split_kloop<256, WGB, true, true, ABL>(lds, 0, GEO::IMG, addr_tab, wr, ks, c + 1 < n_convs ? ks + 72u : 0u, bias + c * NN_COUT, acc, ring);
+            split_kloop<256, WGB, true, true, ABL>(lds, 0, GEO::IMG, addr_tab, wr, ks, c + 1 < n_convs ? ks + 72u : ks_end, bias + c * NN_COUT, acc, ring);
             ks += 72;
             SPSTAMP(sb + 1);
             __syncthreads();                                           // every wave is done reading the images: they are rewritten in place
@@ -260,8 +413,10 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
             SPSTAMP(sb + 4);
             if (MODE != 0 && stamp_now && c == 8 && (threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
         }
+        if constexpr (HEADS) split_heads_tail<WGB>(lds, addr_tab, wr, ks_p1, bias + n_convs * NN_COUT, hp, acc, ring, xres, board0, n_boards);
         // tower output straight from the registers (exact f32): lane = 4 channels of one position per tile, 64-byte pieces
         const int p16 = lane & 15, kg = lane >> 4;
+        if (!HEADS || out)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int row = tile_row<WGB>(j, p16);
@@ -286,30 +441,31 @@ int sz_nn_debug_split_stamps(void* dev_buffer, int32_t mode) { g_split_stamps = 
 // Number of uint16 (bf16) elements of the weight stream of a tower with n_blocks BasicBlocks.
 int64_t sz_nn_split_stream_elems(int32_t n_blocks) {
     if (n_blocks < 0) return SZ_ERR_INVALID;
-    return (int64_t)(36 + 72 * 2 * (int64_t)n_blocks) * SP_KSTEP_U4 * 8;
+    return (int64_t)(36 + 72 * 2 * (int64_t)n_blocks + 8) * SP_KSTEP_U4 * 8;      // stem, 2 convolutions per block, conv_p1 (1x1: 8 k-steps) for the fused heads
 }
 
 // Host-side packing of ONE convolution into its place in the weight stream.
-//   w_in  : [256 co][cin_real][3][3] f32 (BatchNorm folded by the caller)
-//   conv  : 0 = stem (cin_real 119, padded to 128: 36 k-steps), c >= 1: the c-th 256-channel convolution (72 k-steps each)
+//   w_in  : [256 co][cin_real][ksize][ksize] f32 (BatchNorm folded by the caller)
+//   conv  : 0 = stem (cin_real 119, padded to 128: 36 k-steps), c >= 1: the c-th 256-channel 3x3 convolution (72 k-steps each); with ksize 1 and
+//           conv = 1 + 2*n_blocks: conv_p1 of the policy head (8 k-steps behind the tower's)
 //   stream: the whole stream (sz_nn_split_stream_elems elements); k-step record = 16 co tiles x 64 lanes x 8 bf16 of w_hi, then of w_lo,
 //           fragment order of sz_nn_pack_weights16: lane l, elem e <- w[co = tile*16 + (l&15)][ci = k32*32 + 8*(l>>4) + e]
 //   w_hi = bf16(w) (round to nearest even), w_lo = bf16(w - w_hi)
-int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t conv, uint16_t* stream) {
-    if (!w_in || !stream || conv < 0 || conv >= NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
-    const int cin_padded = conv == 0 ? 128 : 256;
+int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream) {
+    if (!w_in || !stream || conv < 0 || conv > NN_MAX_CONVS_SPLIT || (ksize != 1 && ksize != 3) || (ksize == 1 && !(conv & 1))) return SZ_ERR_INVALID;
+    const int cin_padded = conv == 0 ? 128 : 256, taps = ksize * ksize;
     if (cin_real <= 0 || cin_real > cin_padded) return SZ_ERR_INVALID;
     const int ksteps = cin_padded / 32;
     const size_t ks0 = conv == 0 ? 0 : 36 + (size_t)(conv - 1) * 72;
     auto rne = [](float v) -> uint16_t { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < taps; t++)
         for (int k = 0; k < ksteps; k++) {
             uint16_t* rec = stream + (ks0 + (size_t)t * ksteps + k) * SP_KSTEP_U4 * 8;
             for (int tile = 0; tile < 16; tile++)
                 for (int l = 0; l < 64; l++)
                     for (int e = 0; e < 8; e++) {
                         const int co = tile * 16 + (l & 15), ci = k * 32 + 8 * (l >> 4) + e;
-                        const float v = ci < cin_real ? w_in[((size_t)co * cin_real + ci) * 9 + t] : 0.f;
+                        const float v = ci < cin_real ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
                         const uint16_t h = rne(v);
                         const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
                         rec[((size_t)tile * 64 + l) * 8 + e] = h;
@@ -319,40 +475,87 @@ int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t conv, u
     return SZ_OK;
 }
 
-// Split-precision tower (k_tower_split): stem + n_blocks BasicBlocks in one persistent launch.
-//   w_stream: device buffer built with sz_nn_pack_split_stream; bias: device [1 + 2*n_blocks][256] f32; out: device [n_boards][64][256] f32 NHWC.
-int sz_nn_tower_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream) {
-    if (!planes || !w_stream || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
-    StreamDeviceGuard _guard(stream);
+// host: conv_p2.weight [73][256] f32 -> [8 k32-steps]{hi: 5 co tiles x 64 lanes x 8, lo: the same} bf16 (channels 73..79 zero), 8*2*5*64*8 elements
+int sz_nn_pack_split_head(const float* w_in, uint16_t* out) {
+    if (!w_in || !out) return SZ_ERR_INVALID;
+    auto rne = [](float v) -> uint16_t { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    for (int ks = 0; ks < 8; ks++)
+        for (int tile = 0; tile < 5; tile++)
+            for (int l = 0; l < 64; l++)
+                for (int e = 0; e < 8; e++) {
+                    const int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + e;
+                    const float v = co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f;
+                    const uint16_t h = rne(v);
+                    const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
+                    out[((((size_t)ks * 2 + 0) * 5 + tile) * 64 + l) * 8 + e] = h;
+                    out[((((size_t)ks * 2 + 1) * 5 + tile) * 64 + l) * 8 + e] = rne(v - hf);
+                }
+    return SZ_OK;
+}
+
+}  // extern "C"
+
+static int launch_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream,
+                        const SplitHeadsParams* heads) {
     static bool attr_flags[NN_MAX_DEVICES] = {};
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<2>::LDS_BYTES));
+#define SPLIT_ATTR(W, M, H) HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<W, M, H>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<W>::LDS_BYTES))
+        SPLIT_ATTR(1, 0, false); SPLIT_ATTR(2, 0, false); SPLIT_ATTR(1, 0, true); SPLIT_ATTR(2, 0, true);
+        SPLIT_ATTR(2, 1, false); SPLIT_ATTR(2, 2, false); SPLIT_ATTR(2, 3, false); SPLIT_ATTR(2, 4, false);
+#undef SPLIT_ATTR
         attr_set = true;
     }
     const int n_cu = device_cus();
     const bool one = (flags & SZ_NN_SPLIT_WGB1) || (n_boards <= n_cu && !(flags & SZ_NN_SPLIT_WGB2));
-    if (one)
-        hipLaunchKernelGGL((k_tower_split<1, 0>), dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream,
-                           (const uint16_t*)planes, (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, (unsigned long long*)nullptr);
-    else {
-        const int n_tiles = (n_boards + 1) / 2;
-        const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
-#define SPLIT_LAUNCH(M) hipLaunchKernelGGL((k_tower_split<2, M>), grid, dim3(256), SplitGeom<2>::LDS_BYTES, (hipStream_t)stream, (const uint16_t*)planes, (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, g_split_stamps)
-        if (!g_split_stamps) SPLIT_LAUNCH(0);
-        else if (g_split_mode == 2) SPLIT_LAUNCH(2);
-        else if (g_split_mode == 3) SPLIT_LAUNCH(3);
-        else if (g_split_mode == 4) SPLIT_LAUNCH(4);
-        else SPLIT_LAUNCH(1);
+    SplitHeadsParams hp;
+    memset(&hp, 0, sizeof hp);
+    if (heads) hp = *heads;
+    const int n_tiles = one ? n_boards : (n_boards + 1) / 2;
+    const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
+#define SPLIT_LAUNCH(W, M, H, ST) hipLaunchKernelGGL((k_tower_split<W, M, H>), grid, dim3(256), SplitGeom<W>::LDS_BYTES, (hipStream_t)stream, (const uint16_t*)planes, \
+                                                     (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, ST, hp)
+    if (heads) {
+        if (one) SPLIT_LAUNCH(1, 0, true, (unsigned long long*)nullptr); else SPLIT_LAUNCH(2, 0, true, (unsigned long long*)nullptr);
+    } else if (one) SPLIT_LAUNCH(1, 0, false, (unsigned long long*)nullptr);
+    else if (!g_split_stamps) SPLIT_LAUNCH(2, 0, false, (unsigned long long*)nullptr);
+    else if (g_split_mode == 2) SPLIT_LAUNCH(2, 2, false, g_split_stamps);
+    else if (g_split_mode == 3) SPLIT_LAUNCH(2, 3, false, g_split_stamps);
+    else if (g_split_mode == 4) SPLIT_LAUNCH(2, 4, false, g_split_stamps);
+    else SPLIT_LAUNCH(2, 1, false, g_split_stamps);
 #undef SPLIT_LAUNCH
-    }
     HIPCHK(hipGetLastError());
     return SZ_OK;
+}
+
+extern "C" {
+
+// Split-precision tower (k_tower_split): stem + n_blocks BasicBlocks in one persistent launch.
+//   w_stream: device buffer built with sz_nn_pack_split_stream; bias: device [1 + 2*n_blocks (+ 1: conv_p1)][256] f32; out: device [n_boards][64][256] f32 NHWC.
+int sz_nn_tower_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream) {
+    if (!planes || !w_stream || !bias || !out || n_boards <= 0 || n_blocks < 0 || 1 + 2 * n_blocks > NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    return launch_split(planes, w_stream, bias, n_blocks, out, n_boards, flags, stream, nullptr);
+}
+
+int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
+
+// The whole network at the reference's precision class in two launches (network.py:176-192): the tower as above with BOTH heads fused onto each tile while it
+// is still in LDS (conv_p1 -> conv_p2 -> softmax on hi + lo operands; conv_v1 in f32), then the 64 -> 256 -> 1 value MLP (sz_nn_value_mlp).
+//   w_stream / bias: as for sz_nn_tower_split, with conv_p1 (p_norm1 folded) packed as convolution 1 + 2*n_blocks (ksize 1) and its bias as the last row;
+//   w_p2_packed: sz_nn_pack_split_head(conv_p2.weight); b_p2 [73]; wv [256], bv: conv_v1 with v_norm folded; fc1_w_t [64][256], fc1_b [256], fc2_w [256], fc2_b;
+//   probs [n_boards][4672] f32 (softmax iff do_softmax, else logits), value [n_boards], v1_scratch [n_boards][64] f32; tower_out: optional f32 [n_boards][64][256].
+int sz_nn_forward_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, const void* w_p2_packed, const float* b_p2, const float* wv, float bv,
+                        const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value, float* v1_scratch, float* tower_out,
+                        int32_t n_boards, int32_t do_softmax, int32_t flags, void* stream) {
+    if (!planes || !w_stream || !bias || !w_p2_packed || !b_p2 || !wv || !fc1_w_t || !fc1_b || !fc2_w || !probs || !value || !v1_scratch || n_boards <= 0 || n_blocks < 0 ||
+        1 + 2 * n_blocks > NN_MAX_CONVS_SPLIT) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    SplitHeadsParams hp;
+    hp.w_p2 = (const uint4*)w_p2_packed; hp.b_p2 = b_p2; hp.wv = wv; hp.bv = bv; hp.probs = probs; hp.v1_out = v1_scratch; hp.do_softmax = do_softmax;
+    const int rc = launch_split(planes, w_stream, bias, n_blocks, tower_out, n_boards, flags, stream, &hp);
+    if (rc != SZ_OK) return rc;
+    return sz_nn_value_mlp(v1_scratch, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards, stream);
 }
 
 }  // extern "C"

@@ -249,21 +249,29 @@ class SplitPolicyNet:
         # the whole tower's weights as ONE device buffer in k-step order {w_hi fragments, w_lo fragments} (csrc/sz_nn_split.hip), biases [n_convs, 256]
         L = N.lib()
         stream = np.zeros(int(L.sz_nn_split_stream_elems(self.n_blocks)), dtype=np.uint16)
-        for k, (w, b) in enumerate(convs):
-            wk = w.contiguous().cpu().float().numpy()
-            assert wk.shape[0] == 256 and wk.shape[2:] == (3, 3)
-            N.check(L.sz_nn_pack_split_stream(wk.ctypes.data_as(C.c_void_p), wk.shape[1], k, stream.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_stream")
-        self._wstream = torch.from_numpy(stream.view(np.int16)).to(dev)
-        self._bias = torch.stack([b for _, b in convs]).float().contiguous().to(dev)
-        self.force_wgb = 0                                # tests: N.SZ_NN_SPLIT_WGB1 / _WGB2 force one- / two-board workgroups
-        # heads as fp32 GEMMs on the NHWC activation (BatchNorm folded in double): [B*64,256] x [256,256] -> ReLU -> x [256,73]; value 256 -> 1 -> MLP
         wp1, bp1 = _fold_bn(model.conv_p1.weight, model.p_norm1)
+        for k, (w, b) in enumerate(convs + [(wp1, bp1)]):                  # conv_p1 (1x1) rides behind the tower in the stream: the heads are fused onto the tile
+            wk = w.contiguous().cpu().float().numpy()
+            assert wk.shape[0] == 256 and wk.shape[2] == wk.shape[3] == (1 if k == len(convs) else 3)
+            N.check(L.sz_nn_pack_split_stream(wk.ctypes.data_as(C.c_void_p), wk.shape[1], wk.shape[2], k, stream.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_stream")
+        self._wstream = torch.from_numpy(stream.view(np.int16)).to(dev)
+        self._bias = torch.stack([b for _, b in convs] + [bp1]).float().contiguous().to(dev)
+        self.force_wgb = 0                                # tests: N.SZ_NN_SPLIT_WGB1 / _WGB2 force one- / two-board workgroups
+        wp2 = model.conv_p2.weight.detach().view(73, 256).contiguous().cpu().float().numpy()
+        p2 = np.zeros(8 * 2 * 5 * 64 * 8, dtype=np.uint16)
+        N.check(L.sz_nn_pack_split_head(wp2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_head")
+        self._wp2 = torch.from_numpy(p2.view(np.int16)).to(dev)
+        self.fused_heads = True                           # both heads inside the tower launch (sz_nn_forward_split); False: fp32 GEMM heads through torch (cross-check)
+        self._hbuf, self._hcap = None, 0
+        # heads as fp32 GEMMs on the NHWC activation (BatchNorm folded in double): [B*64,256] x [256,256] -> ReLU -> x [256,73]; value 256 -> 1 -> MLP
         self.h_wp1, self.h_bp1 = wp1.view(256, 256).t().contiguous().to(dev), bp1.to(dev)
         self.h_wp2, self.h_bp2 = model.conv_p2.weight.detach().float().view(73, 256).t().contiguous().to(dev), model.conv_p2.bias.detach().float().to(dev)
         wv, bv = _fold_bn(model.conv_v1.weight, model.v_norm)
         self.h_wv, self.h_bv = wv.view(1, 256).t().contiguous().to(dev), bv.to(dev)
+        self._wv_vec, self._bv_f = wv.view(256).contiguous().to(dev), float(bv.view(-1)[0])
         self.h_fc1_w, self.h_fc1_b = model.fc_v1.weight.detach().float().t().contiguous().to(dev), model.fc_v1.bias.detach().float().to(dev)
         self.h_fc2_w, self.h_fc2_b = model.fc_v2.weight.detach().float().t().contiguous().to(dev), model.fc_v2.bias.detach().float().to(dev)
+        self._fc2_vec, self._fc2_b_f = self.h_fc2_w.view(256).contiguous(), float(self.h_fc2_b.view(-1)[0])
         self.module_heads = False                         # True: run policy_head / value_head of the torch module itself (cross-check)
         self._out, self._cap = None, 0
         self._p = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -306,6 +314,25 @@ class SplitPolicyNet:
 
     def _forward(self, planes, inference=True):
         B = planes.shape[0]
+        if self.fused_heads and not self.module_heads:
+            if B > self._hcap:
+                self._hbuf = (torch.empty(B, 4672, dtype=torch.float32, device=self.device), torch.empty(B, dtype=torch.float32, device=self.device),
+                              torch.empty(B, 64, dtype=torch.float32, device=self.device))
+                self._hcap = B
+            policy, value, v1 = (t[:B] for t in self._hbuf)
+            P = lambda t: C.c_void_p(t.data_ptr())
+            flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb
+            ev = None
+            if self.timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            N.check(N.lib().sz_nn_forward_split(P(planes), P(self._wstream), P(self._bias), self.n_blocks, P(self._wp2), P(self.h_bp2), P(self._wv_vec), self._bv_f,
+                                                P(self.h_fc1_w), P(self.h_fc1_b), P(self._fc2_vec), self._fc2_b_f, P(policy), P(value), P(v1), None,
+                                                B, int(bool(inference)), flags, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_forward_split")
+            if ev is not None:
+                ev[1].record()
+                self.timing.append(ev)
+            return policy, value.view(B, 1)
         out = self.tower(planes)
         if self.module_heads:
             x = out.view(B, 8, 8, 256).permute(0, 3, 1, 2)                   # logical NCHW, channels_last memory: no copy

@@ -241,7 +241,7 @@ def test_split_precision_network_matches_fp32_policynn():
         x = (torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
         with torch.no_grad():
             p_ref, v_ref = net(x, inference=False)
-            p, v = split(planes_nchw_to_nhwc128(x), inference=False)
+            p, v = (t.clone() for t in split(planes_nchw_to_nhwc128(x), inference=False))      # the outputs are views of buffers the next call reuses
             y_ref = net.resnet_blocks(torch.relu(net.norm_layer(net.conv1(x))))
             y = split.tower(planes_nchw_to_nhwc128(x)).clone().view(B, 8, 8, 256).permute(0, 3, 1, 2)
             # a board's activation does not depend on the workgroup form (one or two boards per workgroup) nor on its neighbours: bit for bit
@@ -260,8 +260,30 @@ def test_split_precision_network_matches_fp32_policynn():
             pi, _ = split(planes_nchw_to_nhwc128(x), inference=True)
             pi_ref, _ = net(x, inference=True)
         assert float((pi.log() - pi_ref.log()).abs().max()) < 1e-4 and bool((pi.argmax(1) == pi_ref.argmax(1)).all())
-    # the module's own heads on the split tower's output give the same numbers as the GEMM-form heads
+    # the module's own heads and the fp32 GEMM heads (torch) on the split tower's output give the numbers of the fused heads
     split.module_heads = True
     with torch.no_grad():
-        p2, v2 = split(planes_nchw_to_nhwc128(x), inference=False)
-    assert float((p2 - p).abs().max()) < 1e-5 and float((v2 - v).abs().max()) < 1e-6
+        p2, v2 = (t.clone() for t in split(planes_nchw_to_nhwc128(x), inference=False))
+    split.module_heads, split.fused_heads = False, False
+    with torch.no_grad():
+        p3, v3 = (t.clone() for t in split(planes_nchw_to_nhwc128(x), inference=False))
+    split.fused_heads = True
+    assert float((p2 - p3).abs().max()) < 1e-5 and float((v2 - v3).abs().max()) < 1e-6
+    assert float((c(p) - c(p3)).norm() / c(p3).norm()) < 5e-5 and float((v - v3).abs().max()) < 1e-5
+    # fused heads: a board's policy and value do not depend on the workgroup form, on the batch size or on its neighbours — bit for bit
+    with torch.no_grad():
+        planes = planes_nchw_to_nhwc128(x)
+        outs = []
+        for inference in (True, False):
+            split.force_wgb = N.SZ_NN_SPLIT_WGB1
+            pa, va = (t.clone() for t in split(planes, inference=inference))
+            split.force_wgb = N.SZ_NN_SPLIT_WGB2
+            pb, vb = (t.clone() for t in split(planes, inference=inference))
+            pr, vr = (t.clone().flip(0) for t in split(planes.flip(0).contiguous(), inference=inference))
+            split.force_wgb = 0
+            ps, vs = (t.clone() for t in split(planes[5:6], inference=inference))                 # one board alone
+            p37, v37 = (t.clone() for t in split(planes[:37], inference=inference))               # one board per workgroup (37 <= #CUs)
+            assert torch.equal(pa, pb) and torch.equal(va, vb) and torch.equal(pb, pr) and torch.equal(vb, vr)
+            assert torch.equal(ps[0], pa[5]) and torch.equal(vs[0], va[5]) and torch.equal(p37, pa[:37]) and torch.equal(v37, va[:37])
+            if inference:
+                assert torch.allclose(pa.sum(1), torch.ones(B, device="cuda"), atol=1e-5)
