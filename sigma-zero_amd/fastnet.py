@@ -226,9 +226,12 @@ class SplitPolicyNet:
 
     network.py is fp32 end to end.  FastPolicyNet's bf16 operands keep 8 bits of mantissa (search-level effect measured in
     tests/test_gpu_train_and_precision.py: single visits move).  Here every tower operand is carried as two bf16 numbers, x = hi + lo
-    (16 bits), every product as three MFMAs (hi*hi + hi*lo + lo*hi) with f32 accumulation, the residual and BatchNorm-folded bias in f32;
-    the heads run in fp32 through the torch module itself.  About 3x the time of the bf16 tower, ~7x faster than the fp32 torch/MIOpen
-    forward, logits within ~1e-5 relative of it.  Input: the engine's bit-packed planes ("bits128") or the bf16 NHWC image ("nhwc128")."""
+    (16 bits), every product as three MFMAs (hi*hi + lo*hi + hi*lo) with f32 accumulation, the residual and BatchNorm-folded bias in f32;
+    both heads run inside the same launch on the tile while it is still in LDS (conv_p1 / conv_p2 on hi + lo operands, conv_v1 and the value
+    MLP in f32; `fused_heads=False`: fp32 GEMMs through torch, `module_heads=True`: the module's own heads — cross-checks).  About 2.6x the
+    time of the bf16 tower, 10x faster than the fp32 torch/MIOpen forward, logits within ~1e-5 relative of it; a board's outputs do not depend
+    on the batch it is evaluated in (bit for bit).  Input: the engine's bit-packed planes ("bits128") or the bf16 NHWC image ("nhwc128").
+    The returned tensors are views of buffers that the next call reuses."""
 
     def __init__(self, model, device=None):
         model = model.eval()

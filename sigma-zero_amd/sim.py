@@ -58,8 +58,11 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
 
     The games run concurrently on `n_boards` board slots of one engine (default: one slot per game).  A slot whose game ends is
     REFILLED with the next game that has not started yet, so the GPU stays full until fewer than n_boards games remain; from then
-    on the batch is COMPACTED (sz_compact): the network only evaluates the boards that still play.  Per-game results do not depend
-    on the slot a game runs in or on what runs beside it.
+    on the batch is COMPACTED (sz_compact): the network only evaluates the boards that still play.  With the MFMA networks
+    (FastPolicyNet, SplitPolicyNet) a game's results do not depend on the slot it runs in, on the batch size or on what runs beside it —
+    bit for bit (their kernels are per board and every reduction has a fixed order; tests/test_gpu_train_and_precision.py).  A plain
+    torch module goes through MIOpen / hipBLASLt, whose algorithm choice and hence rounding can change with the batch size: there the
+    records are reproducible for a fixed (n_games, n_boards) schedule only; pass compact=False to keep the batch size constant.
 
     scharnagl: start index per game (default: python `random.randint(0,959)` per game like chess_tensor.py:69, drawn in game order).
     uniforms(game, ply) -> float: the np.random.random_sample() draw of sim.py:68.  Default: the global numpy RNG, drawn once per ply

@@ -145,16 +145,19 @@ def test_split_precision_network_searches_like_fp32():
 
 
 # ------------------------------------------------------------------------------------------------ 3. ragged self-play: refill + compaction
-def test_refill_and_compaction_give_identical_per_game_records():
+@pytest.mark.parametrize("kind,n_games,n_slots", [("fast", 12, 5), ("split", 12, 5), ("split", 300, 130)])
+def test_refill_and_compaction_give_identical_per_game_records(kind, n_games, n_slots):
     """sim.py:102-123 plays exactly num_games games.  The product runs them on fewer board slots than games (slot refill) and evaluates
     only the boards that still play (compaction); per-game records must be bit-identical to the plain run (one slot per game, no
-    compaction), because a game's results do not depend on what runs beside it."""
+    compaction), because a game's results do not depend on what runs beside it.  Both MFMA networks: the bf16 tower (strictly per-board kernels)
+    and the split-precision network, whose 300-game case also crosses from two boards per workgroup (300 boards) to one (130 and fewer)."""
+    from sigma_zero_amd.fastnet import SplitPolicyNet
     torch.manual_seed(0)
-    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
-    args = {"C": 2, "num_searches": 10}
-    n_games = 12
-    sch = [3 * g + 5 for g in range(n_games)]
-    caps = [6, 9, 14, 40, 11, 40, 7, 40, 25, 40, 40, 13]                     # ragged: games are cut at different plies (stand-in for different game lengths)
+    net = sz.policyNN({}).cuda().eval()
+    fast = FastPolicyNet(net) if kind == "fast" else SplitPolicyNet(net)
+    args = {"C": 2, "num_searches": 10 if n_games == 12 else 4}
+    sch = [(3 * g + 5) % 960 for g in range(n_games)]
+    caps = [6, 9, 14, 40, 11, 40, 7, 40, 25, 40, 40, 13] if n_games == 12 else [3 + (g * 7) % 6 for g in range(n_games)]    # ragged: games are cut at different plies (stand-in for different game lengths)
 
     def uni(g, ply):
         return ((g * 7919 + ply * 104729) % 1000003) / 1000003.0
@@ -166,7 +169,7 @@ def test_refill_and_compaction_give_identical_per_game_records():
         return games, st
 
     plain, st_plain = run(compact=False)
-    packed, st_packed = run(n_boards=5, compact=True)
+    packed, st_packed = run(n_boards=n_slots, compact=True)
     assert len(plain) == len(packed) == n_games
     for g in range(n_games):
         a, b = plain[g], packed[g]
@@ -177,8 +180,9 @@ def test_refill_and_compaction_give_identical_per_game_records():
         for x, y in zip(a["actions"], b["actions"]):
             assert list(x.keys()) == list(y.keys()) and list(x.values()) == list(y.values())
     assert st_plain["sims"] == st_packed["sims"]                       # the same work was done ...
-    assert st_packed["nn_rows"] <= st_packed["sims"] + 10 * 2 * st_packed["plies"]      # ... on network batches that held (almost) only live boards
-    assert st_plain["nn_rows"] == 12 * 10 * st_plain["plies"]
+    S = args["num_searches"]
+    assert st_packed["nn_rows"] <= st_packed["sims"] + S * 2 * st_packed["plies"]       # ... on network batches that held (almost) only live boards
+    assert st_plain["nn_rows"] == n_games * S * st_plain["plies"]
 
 
 # ------------------------------------------------------------------------------------------------ 4. subtree reuse (non-reference option)
