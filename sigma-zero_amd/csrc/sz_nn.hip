@@ -418,6 +418,21 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     }
 }
 
+// Byte offset of the 8-byte epilogue slot (image row, 4 channels from co) inside a 16x16x32-path image.  The 16 lanes of a ds_write_b64 group hold 16 rows
+// at one channel offset; at the 544-B pitch 8 B x (68 row) mod 128 B takes 4 values, so the store is 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT: 17 % of the
+// LDS-array cycles of the tower).  NN_EPI_NOCONFLICT=1 is a TIMING-ONLY A/B build (results garbage): the same stores and residual reads go to conflict-free
+// addresses (the 16 lanes contiguous), which prices the conflicts in in-kernel cycles (tools/tower_stamps.py; profiles/r03g_*).
+#ifndef NN_EPI_NOCONFLICT
+#define NN_EPI_NOCONFLICT 0
+#endif
+__device__ __forceinline__ int epi_slot16(int row, int co) {
+#if NN_EPI_NOCONFLICT
+    return ((row >> 3) & 7) * 8192 + (co >> 2) * 128 + (((row >> 6) << 3) | (row & 7)) * 8;
+#else
+    return row * (NN_COUT * 2 + NN_PAD16) + co * 2;
+#endif
+}
+
 // Staged epilogue functors for conv_kloop16's split last tap: tile p = i*4 + j (channel tile i, position tile j of the first half) in stages
 //   -1: operand prefetch (residual only)   0: accumulator read-out   1, 2: bf16 pack (+ residual) + ReLU of one register pair each   3: LDS write
 template <int WGB> struct EpiTile16 {
@@ -431,7 +446,7 @@ template <int WGB> struct EpiTile16 {
         else if (st == 3) {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
-            *(uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2) = o;
+            *(uint2*)(img + epi_slot16(row, co)) = o;
         }
     }
 };
@@ -442,7 +457,7 @@ template <int WGB> struct EpiResidual16 {
         const int i = p / (2 * WGB), j = p % (2 * WGB);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
-        return (uint2*)(img + row * (NN_COUT * 2 + NN_PAD16) + co * 2);
+        return (uint2*)(img + epi_slot16(row, co));
     }
     __device__ __forceinline__ void operator()(int p, int st) {
         const int i = p / (2 * WGB), j = p % (2 * WGB);
@@ -465,7 +480,7 @@ __device__ __forceinline__ void acc_tile_to_lds16(unsigned char* lds, const f32x
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
     if (relu) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
-    *(uint2*)(lds + row * OPITCH + co * 2) = o;
+    *(uint2*)(lds + epi_slot16(row, co)) = o;
 }
 // the same with the residual: x <- relu(acc + x) in place on the LDS image (f32 add, one bf16 rounding)
 template <int WGB>
@@ -474,7 +489,7 @@ __device__ __forceinline__ void acc_tile_residual16(unsigned char* xlds, const f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
     const f32x4 v = acc[i][j];
-    uint2* px = (uint2*)(xlds + row * OPITCH + co * 2);
+    uint2* px = (uint2*)(xlds + epi_slot16(row, co));
     const uint2 r = *px;
     uint2 o;
     o.x = relu_bf16x2(pack_bf16x2(v[0] + bf16_lo(r.x), v[1] + bf16_hi(r.x)));

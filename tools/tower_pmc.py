@@ -15,6 +15,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "bits":          # the engine's bit-pack
 if len(sys.argv) > 3 and sys.argv[3] == "split":          # the split-precision tower (k_tower_split) instead
     from sigma_zero_amd.fastnet import SplitPolicyNet
     fast = SplitPolicyNet(sz.policyNN({}).cuda().eval())
+if len(sys.argv) > 4:                                     # diagnostic build of the bf16 tower under the counters: 3 = no LDS fragment reads in the K loop, ...
+    import ctypes as C
+    from sigma_zero_amd import _native as N
+    stamps = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+    N.check(N.lib().sz_nn_debug_tower_stamps(C.c_void_p(stamps.data_ptr()), int(sys.argv[4])), "stamps")
 for _ in range(12):
     fast.tower(planes)
 torch.cuda.synchronize()
