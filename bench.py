@@ -21,6 +21,7 @@ One JSON line is printed by rank 0.  Extra objects:
   roofline_split the same workload with the network at the REFERENCE's precision class on the matrix cores (SplitPolicyNet / k_tower_split: hi + lo
                 bf16 operands, 3 MFMAs per product — the configuration that meets north_star's 1e-4 on visit policies): 1 warm-up + 3 timed plies,
                 simulations/s, launch duration of k_tower_split by HIP events, algorithmic AND issued MFMA fraction of the 2.5 PFLOP/s peak (N=1 only)
+  fp16_config   the same workload on f16 operands (the product API's default self-play network; one timed ply, N=1 only)
   parity_config simulations/s of the same boards-per-GPU with the fp32 network the reference uses (bounded sample, N=1 only)
 `--gpus N` with N > 1 outside a launcher (no RANK in the environment) starts N ranks itself (torch.distributed.run on 127.0.0.1) before any GPU call,
 as the reference spawns its own self-play workers (train_RL.py:215-227); under a launcher WORLD_SIZE must equal --gpus.
@@ -214,6 +215,48 @@ def split_sample(dev, B, S, chess960, plies=3, warmup=1):
             "config": {"workload": "selfplay_%dboards_%dsearches" % (B, S), "network": "SplitPolicyNet (reference precision class: identical visit counts to the fp32 network in tests)"}}
 
 
+def fp16_sample(dev, B, S, chess960):
+    """The headline workload on f16 operands (FastPolicyNet(operands="fp16"): the product API's default self-play network): 1 warm-up + 1 timed ply."""
+    import random
+    import sigma_zero_amd as sz
+    from sigma_zero_amd.selfplay import SelfPlayEngine
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    torch.manual_seed(0)
+    model = FastPolicyNet(sz.policyNN({}).eval(), device=dev, operands="fp16")
+    eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(chess960), learning=True, device=dev, planes_dtype="bits128")
+    prng, rng = random.Random(0), np.random.RandomState(98)
+    eng.new_games([prng.randrange(960) if chess960 else -1 for _ in range(B)])
+    events = []
+
+    @torch.no_grad()
+    def ply(timed):
+        eng.begin()
+        for it in range(S):
+            model.timing = events if (timed and it % 50 == 25) else None
+            policy, value = model(eng.planes, inference=True)
+            eng.step(policy, value.reshape(-1))
+        model.timing = None
+        eng.play(rng.random_sample(B))
+        eng.fetch_ply()
+
+    ply(False)
+    st0 = eng.check_errors()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ply(True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st1 = eng.check_errors()
+    eng.close()
+    sims = st1["simulations"] - st0["simulations"]
+    ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    flop = 2.0 * B * 64 * 256 * 9 * (119 + 38 * 256)
+    return {"value": sims / dt, "unit": "simulations/s", "dtype": "f16", "network": "FastPolicyNet(operands='fp16'): k_tower16_bf16<ElemF16> + fused heads",
+            "sample": "%d boards x num_searches=%d, one ply after one warm-up ply, %d simulations in %.2f s" % (B, S, sims, dt),
+            "tower_launch_ms": ms, "tower_frac_of_mfma_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "fidelity": "64/64 test positions with the fp32 network's exact visit counts at 100 and 800 searches (bf16: 61-62/64); tests/test_gpu_train_and_precision.py"}
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) before anything in this process has touched the GPU, relay their output
     (rank 0 prints the JSON line) and return their exit code.  The reference spawns its own workers the same way (train_RL.py:215-227)."""
@@ -238,6 +281,8 @@ def main():
     ap.add_argument("--chess960", type=int, default=0)
     ap.add_argument("--net", default="fast", choices=["fast", "torch", "split"],
                     help="fast: hand-written bf16 MFMA tower (csrc/sz_nn.hip); split: the same on hi+lo bf16 operands (reference precision class); torch: MIOpen/ATen kernels")
+    ap.add_argument("--operands", default="bf16", choices=["bf16", "fp16"],
+                    help="MFMA operand element of --net fast: bf16 (BASELINE.json's configuration) or fp16 (11 bits of mantissa, same cycles, ~5 %% lower clock)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N>1 path on one GPU)")
     ap.add_argument("--planes", default="bits128", choices=["bits128", "nhwc128"],
                     help="network-input image written by the tree kernel on the fast path: bit-packed (1 KiB/board) or bf16 NHWC (16 KiB/board)")
@@ -282,7 +327,7 @@ def main():
     B, S = a.boards, a.searches
     if fast:
         from sigma_zero_amd.fastnet import FastPolicyNet, SplitPolicyNet
-        model = SplitPolicyNet(sz.policyNN({}).eval().to(dev), device=dev) if split else FastPolicyNet(sz.policyNN({}).eval(), device=dev)
+        model = SplitPolicyNet(sz.policyNN({}).eval().to(dev), device=dev) if split else FastPolicyNet(sz.policyNN({}).eval(), device=dev, operands=a.operands)
         eng = SelfPlayEngine(model, {"C": 2, "num_searches": S}, B, chess960=bool(a.chess960), learning=True, device=dev, planes_dtype=a.planes, edges_per_board=a.edges_per_board)
     else:
         model = sz.policyNN({}).eval().to(dev).to(dtype).to(memory_format=torch.channels_last)
@@ -358,7 +403,7 @@ def main():
         out = {
             "metric": "MCTS simulations/sec (self-play)", "value": total_sims / dt_max, "unit": "simulations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / max(a.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2" if split else ("bf16" if dtype == torch.bfloat16 else "f32"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2" if split else (("f16" if (fast and a.operands == "fp16") else "bf16") if dtype == torch.bfloat16 else "f32"),
             "data": "synthetic (seeded random-init policyNN weights, self-play from %s start positions)" % ("Chess960" if a.chess960 else "classical"),
             "config": {"workload": "selfplay_%dboards_%dsearches" % (B, S), "boards_per_gpu": B, "num_searches": S, "C": 2,
                        "learning": True, "chess960": bool(a.chess960), "step": "one ply = full search of every board + sample + play",
@@ -420,7 +465,7 @@ def main():
                 except Exception:
                     pass
                 out["roofline"] = {"kernel": "k_tower_split (persistent, hi+lo bf16 operands: 3 MFMAs per algorithmic product)" if split
-                                   else "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS)" if whole
+                                   else "k_tower16_bf16 (persistent: stem + 19 BasicBlocks per launch, activations resident in LDS; %s operands)" % a.operands if whole
                                    else "k_block16_bf16<2> (fused BasicBlock: conv3x3+BN+ReLU -> LDS -> conv3x3+BN+residual+ReLU, 16x16x32 MFMA)" if fused
                                    else "k_conv_bf16<256,9,2> (fused 3x3 conv + folded BN + bias + residual + ReLU)", "bound": "mfma",
                                    "achieved": ctf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ctf / MFMA_BF16_PEAK_TFLOPS,
@@ -443,6 +488,11 @@ def main():
                 out["roofline_split"] = split_sample(dev, B, S, a.chess960, plies=a.split_plies)
             except Exception as ex:                     # noqa: BLE001
                 out["roofline_split"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
+        if not a.no_split and world == 1 and fast and not split and a.operands == "bf16":
+            try:
+                out["fp16_config"] = fp16_sample(dev, B, S, a.chess960)
+            except Exception as ex:                     # noqa: BLE001
+                out["fp16_config"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
         if not a.no_parity_config and world == 1 and fast:
             try:
                 out["parity_config"] = parity_config_sample(dev, B, a.chess960)

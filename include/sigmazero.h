@@ -187,6 +187,12 @@ int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, 
 int sz_nn_pack_weights(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
 
 int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
+/* f16 operands instead of bf16 for sz_nn_tower_bf16 (in `flags`) and sz_nn_heads_bf16 (or-ed into `do_softmax`): v_mfma_f32_16x16x32_f16 runs at the bf16
+ * rate and f16 keeps 11 bits of mantissa instead of 8; activations and BatchNorm-folded weights of this network are O(1), far inside f16's range.  The
+ * weights are then packed with the _f16 packers, the tower output / heads input [n_boards,64,256] holds f16 bit patterns. */
+#define SZ_NN_F16 0x8000000
+int sz_nn_pack_weights16_f16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out);
+int sz_nn_pack_head16_f16(const float* w_in, uint16_t* out);
 
 /* The whole tower (network.py:176-184: stem conv + n_blocks BasicBlocks) in ONE persistent launch: a workgroup keeps its
  * boards' activations in LDS through all 1 + 2*n_blocks convolutions; only weights stream.  planes [n_boards,64,128] bf16

@@ -11,6 +11,7 @@ SZ_PLANES_F32, SZ_PLANES_BF16, SZ_PLANES_NHWC128_BF16, SZ_PLANES_NHWC128_BITS = 
 SZ_NN_W16 = 0x40000
 SZ_NN_IN_BITS = 0x1000000
 SZ_NN_SPLIT_WGB1, SZ_NN_SPLIT_WGB2 = 0x2000000, 0x4000000
+SZ_NN_F16 = 0x8000000
 
 
 class sz_config(C.Structure):
@@ -69,6 +70,8 @@ EXPORTS = {
     "sz_nn_heads_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int32] * 2 + [C.c_void_p]),
     "sz_nn_value_head_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "sz_nn_pack_head16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sz_nn_pack_head16_f16": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sz_nn_pack_weights16_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_pack_weights16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_pack_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_error_string": (C.c_char_p, [C.c_int]),

@@ -158,6 +158,10 @@ __device__ __forceinline__ void lds_to_out(const unsigned char* lds, const uint1
     for (int c = tid; c < OUT_CHUNKS; c += 256) {
         if (c >= valid) break;
         uint4 v = *(const uint4*)(lds + (c >> 5) * OPITCH + (c & 31) * 16);
+        if (!res4 && !relu) {                              // plain copy (the persistent tower's output): element type does not matter
+            if (NTS) st_stream(out4 + c, v); else out4[c] = v;
+            continue;
+        }
         float f[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
         if (res4) {
             uint4 r = NT ? ld_stream(res4 + c) : res4[c];
@@ -200,7 +204,8 @@ __device__ __forceinline__ void conv_prefetch16(const uint4* __restrict__ w, uin
 
 
 template <int CIN, int NTAPS, int WGB, int RING = 2, bool PREFETCHED = false, int ABL = 0 /* timing ablation: 1 = no weight loads, 2 = no LDS reads in the loop */,
-          bool ACCUM = false /* add onto the accumulators as they are (second / third pass of a split-precision convolution): no bias, no initialisation */,
+          bool ACCUM = false /* add onto the accumulators as they are: no bias, no initialisation */,
+          class E = ElemBF16 /* operand element: ElemBF16 or ElemF16 (sz_nn_common.h) */,
           class EPI = std::nullptr_t /* callable (p, stage): stage -1..3 of the epilogue of accumulator tile p = i*NH + j of the FIRST position half (EpiTile16 /
                                         EpiResidual16); when given, the LAST tap runs its two position halves one after the other and the epilogue of the first
                                         half rides in the MFMA gaps of the second */>
@@ -312,7 +317,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
                         if (!((SK == 1 && hs == 0 && j == 0) || (SK == 2 && hs == 1 && j == NH - 1)))
-                            acc[i][hs * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j], 0, 0, 0);
+                            acc[i][hs * NH + j] = E::mfma(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j]);
                         if (NN_ILV) {
                             // one memory instruction per MFMA gap (an MFMA leaves 8 of its 16 cycles for other issue): first the next
                             // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2)
@@ -354,7 +359,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = E::mfma(a, bfrag[kc & 1][j], acc[i][j]);
                         const int m = i * NH + j;
                         if (m < NH) {
                             if (ABL & 2) {}
@@ -379,7 +384,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
                         if (!(SKIPROWS && j == NH - 1))                                           // the last tap looks one row down: board row 7 reads only zeros
-                            acc[i][NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[kc & 1][j], acc[i][NH + j], 0, 0, 0);
+                            acc[i][NH + j] = E::mfma(a, bfrag[kc & 1][j], acc[i][NH + j]);
                         const int m = i * NH + j;
                         if (m < NH) {
                             if (!(ABL & 2) && kc + 1 < KSTEPS && !(SKIPROWS && m == NH - 1)) bfrag[(kc + 1) & 1][m] = LD(bcur[NH + m] + (kc + 1) * 64);
@@ -435,14 +440,14 @@ __device__ __forceinline__ int epi_slot16(int row, int co) {
 
 // Staged epilogue functors for conv_kloop16's split last tap: tile p = i*4 + j (channel tile i, position tile j of the first half) in stages
 //   -1: operand prefetch (residual only)   0: accumulator read-out   1, 2: bf16 pack (+ residual) + ReLU of one register pair each   3: LDS write
-template <int WGB> struct EpiTile16 {
+template <int WGB, class E = ElemBF16> struct EpiTile16 {
     unsigned char* img; const f32x4 (&acc)[4][4 * WGB]; f32x4 tv; uint2 o;
     __device__ __forceinline__ EpiTile16(unsigned char* img_, const f32x4 (&acc_)[4][4 * WGB]) : img(img_), acc(acc_) {}
     __device__ __forceinline__ void operator()(int p, int st) {
         const int i = p / (2 * WGB), j = p % (2 * WGB);
         if (st == 0) tv = acc[i][j];
-        else if (st == 1) o.x = relu_bf16x2(pack_bf16x2(tv[0], tv[1]));
-        else if (st == 2) o.y = relu_bf16x2(pack_bf16x2(tv[2], tv[3]));
+        else if (st == 1) o.x = relu_bf16x2(E::pack2(tv[0], tv[1]));
+        else if (st == 2) o.y = relu_bf16x2(E::pack2(tv[2], tv[3]));
         else if (st == 3) {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
@@ -450,7 +455,7 @@ template <int WGB> struct EpiTile16 {
         }
     }
 };
-template <int WGB> struct EpiResidual16 {
+template <int WGB, class E = ElemBF16> struct EpiResidual16 {
     unsigned char* img; const f32x4 (&acc)[4][4 * WGB]; f32x4 tv; uint2 o; uint2 rr[3];     // residual operands ride two tiles ahead of their use
     __device__ __forceinline__ EpiResidual16(unsigned char* img_, const f32x4 (&acc_)[4][4 * WGB]) : img(img_), acc(acc_) {}
     __device__ __forceinline__ uint2* slot(int p) const {
@@ -463,27 +468,27 @@ template <int WGB> struct EpiResidual16 {
         const int i = p / (2 * WGB), j = p % (2 * WGB);
         if (st == -1) rr[p % 3] = *slot(p);
         else if (st == 0) { tv = acc[i][j]; if (p + 2 < 8 * WGB) rr[(p + 2) % 3] = *slot(p + 2); }
-        else if (st == 1) o.x = relu_bf16x2(pack_bf16x2(tv[0] + bf16_lo(rr[p % 3].x), tv[1] + bf16_hi(rr[p % 3].x)));
-        else if (st == 2) o.y = relu_bf16x2(pack_bf16x2(tv[2] + bf16_lo(rr[p % 3].y), tv[3] + bf16_hi(rr[p % 3].y)));
+        else if (st == 1) o.x = relu_bf16x2(E::pack2(tv[0] + E::lo(rr[p % 3].x), tv[1] + E::hi(rr[p % 3].x)));
+        else if (st == 2) o.y = relu_bf16x2(E::pack2(tv[2] + E::lo(rr[p % 3].y), tv[3] + E::hi(rr[p % 3].y)));
         else if (st == 3) *slot(p) = o;
     }
 };
 
 // epilogue of ONE accumulator tile (channel tile i, position tile j): relu?(acc) -> bf16 -> LDS image (the accumulators started at the bias)
-template <int WGB>
+template <int WGB, class E = ElemBF16>
 __device__ __forceinline__ void acc_tile_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], int i, int j, bool relu) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = tile_row<WGB>(j, lane & 15), co = (wave * 4 + i) * 16 + 4 * (lane >> 4);
     const f32x4 v = acc[i][j];
     uint2 o;
-    o.x = pack_bf16x2(v[0], v[1]);
-    o.y = pack_bf16x2(v[2], v[3]);
+    o.x = E::pack2(v[0], v[1]);
+    o.y = E::pack2(v[2], v[3]);
     if (relu) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
     *(uint2*)(lds + epi_slot16(row, co)) = o;
 }
 // the same with the residual: x <- relu(acc + x) in place on the LDS image (f32 add, one bf16 rounding)
-template <int WGB>
+template <int WGB, class E = ElemBF16>
 __device__ __forceinline__ void acc_tile_residual16(unsigned char* xlds, const f32x4 (&acc)[4][4 * WGB], int i, int j) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -492,13 +497,13 @@ __device__ __forceinline__ void acc_tile_residual16(unsigned char* xlds, const f
     uint2* px = (uint2*)(xlds + epi_slot16(row, co));
     const uint2 r = *px;
     uint2 o;
-    o.x = relu_bf16x2(pack_bf16x2(v[0] + bf16_lo(r.x), v[1] + bf16_hi(r.x)));
-    o.y = relu_bf16x2(pack_bf16x2(v[2] + bf16_lo(r.y), v[3] + bf16_hi(r.y)));
+    o.x = relu_bf16x2(E::pack2(v[0] + E::lo(r.x), v[1] + E::hi(r.x)));
+    o.y = relu_bf16x2(E::pack2(v[2] + E::lo(r.y), v[3] + E::hi(r.y)));
     *px = o;
 }
 
 // bias == nullptr: the accumulators already started at the bias (conv_kloop16's `bias` argument)
-template <int WGB>
+template <int WGB, class E = ElemBF16>
 __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&acc)[4][4 * WGB], const float* __restrict__ bias, bool relu) {
     constexpr int OPITCH = NN_COUT * 2 + NN_PAD16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -512,8 +517,8 @@ __device__ __forceinline__ void acc_to_lds16(unsigned char* lds, const f32x4 (&a
             f32x4 v = acc[i][j];
             if (bias) v += *(const f32x4*)(bias + co);      // (no "+ 0.f" otherwise: it is not a no-op for -0 and would stay in the code)
             uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = E::pack2(v[0], v[1]);
+            o.y = E::pack2(v[2], v[3]);
             if (relu) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); }
             *(uint2*)(lds + row * OPITCH + co * 2) = o;
         }
@@ -789,6 +794,7 @@ __global__ __launch_bounds__(256) void k_value_head(const uint16_t* __restrict__
 //           the board's 4672 logits -> probs f32 in the reference's flatten order [plane*64 + pos].
 // Replaces k_conv16<256,1> + k_policy_head + the x-reading part of k_value_head: x is read once (134 MB at B = 4096) instead of
 // three passes over 134 MB plus a 134 MB intermediate written and re-read.
+template <class E /* operand element of x, t and the packed weights: ElemBF16 or ElemF16 */>
 __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restrict__ x, const uint4* __restrict__ w_p1, const float* __restrict__ b_p1,
                                                           const uint4* __restrict__ w_p2, const float* __restrict__ b_p2, const float* __restrict__ wv, float bv,
                                                           float* __restrict__ probs, float* __restrict__ v1_out, int n_boards, int do_softmax) {
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const uint2 v = *(const uint2*)(lds + (wave * 32 + r) * PITCH + lane * 8);
-            part[r] = bf16_lo(v.x) * wv4.x + bf16_hi(v.x) * wv4.y + bf16_lo(v.y) * wv4.z + bf16_hi(v.y) * wv4.w;
+            part[r] = E::lo(v.x) * wv4.x + E::hi(v.x) * wv4.y + E::lo(v.y) * wv4.z + E::hi(v.y) * wv4.w;
         }
 #pragma unroll
         for (int m = 32, n = 16; m >= 2; m >>= 1, n >>= 1) {
@@ -823,9 +829,9 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
         if (!(lane & 1) && board < n_boards) v1_out[(size_t)board * 64 + (row & 63)] = fmaxf(tot + bv, 0.f);
     }
     f32x4 acc[4][4 * WGB];
-    conv_kloop16<256, 1, WGB>(lds, w_p1, acc, false, false, nullptr, 0, b_p1);
+    conv_kloop16<256, 1, WGB, 2, false, 0, false, E>(lds, w_p1, acc, false, false, nullptr, 0, b_p1);
     __syncthreads();
-    acc_to_lds16<WGB>(lds, acc, nullptr, true);               // t over x, in the layout the MFMA B operand is read from
+    acc_to_lds16<WGB, E>(lds, acc, nullptr, true);            // t over x, in the layout the MFMA B operand is read from
     __syncthreads();
     // policy logits: wave -> board wave>>1, position tiles 2*(wave&1) + {0,1}; 5 channel tiles (73 padded to 80), K = 256
     const int pboard = wave >> 1, j0 = (wave & 1) * 2;
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void k_heads16_bf16(const uint16_t* __restr
 #pragma unroll
         for (int i = 0; i < 5; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) pa[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], pa[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; j++) pa[i][j] = E::mfma(a[i], b[j], pa[i][j]);
     }
     // lane holds logits of positions (j0+j)*16 + p16, channels i*16 + 4*kg + r
     float mx = -3.0e38f;
@@ -959,7 +965,7 @@ struct TowerParams {
 // STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
 // a buffer of their own; the shipped instantiation (STAMP = false) executes no stamp.
 #define TSTAMP(k) do { if (STAMP_ && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
-template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 1/2/3 (results garbage) */>
+template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 1/2/3 (results garbage) */, class E = ElemBF16 /* operand element: bf16 or f16 */>
 __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags,
                                                           unsigned long long* __restrict__ stamps) {
     constexpr bool STAMP_ = MODE != 0;
@@ -996,19 +1002,19 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             for (int spins = 0; spins < 512 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) __builtin_amdgcn_s_sleep(2);
         }
         __syncthreads();                                               // previous tile's output image fully read
-        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(bufT, planes, board0, n_boards);
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16, E>(bufT, planes, board0, n_boards);
         else stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
         __syncthreads();
-        conv_kloop16<128, 9, WGB, 4, true>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0]);  // stem (reads bufT): x = relu(bn(conv1(planes)))
+        conv_kloop16<128, 9, WGB, 4, true, 0, false, E>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0]);  // stem (reads bufT): x = relu(bn(conv1(planes)))
         if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
-        acc_to_lds16<WGB>(bufX, acc, nullptr, true);
+        acc_to_lds16<WGB, E>(bufX, acc, nullptr, true);
         __syncthreads();
         for (int blk = 0; blk < n_blocks; blk++) {
             const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
             TSTAMP(0);
             wave_stagger();
-            auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB>(bufT, acc));
+            auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB, E>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
+            conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB, E>(bufT, acc));
             TSTAMP(1);
             conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
 #pragma unroll
@@ -1019,8 +1025,8 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             __syncthreads();
             TSTAMP(3);
             wave_stagger();
-            auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
-            conv_kloop16<256, 9, WGB, 4, true, ABL>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB>(bufX, acc));   // reads bufT
+            auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB, E>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
+            conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB, E>(bufX, acc));   // reads bufT
             TSTAMP(4);
             if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
 #pragma unroll
@@ -1103,6 +1109,34 @@ template <int WGB> static int launch_block16(const void* in, const void* w1, con
     return SZ_OK;
 }
 
+// host-side weight packing into MFMA A-fragment order of the 16x16x32 path, for either operand element
+template <class E> static int pack_weights16_impl(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out) {
+    if (!w_in || !out || (ksize != 1 && ksize != 3) || cin_padded % 32 || cin_real > cin_padded) return SZ_ERR_INVALID;
+    const int taps = ksize * ksize, ksteps = cin_padded / 32;
+    for (int t = 0; t < taps; t++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int tile = 0; tile < 16; tile++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
+                        float v = (ci < cin_real) ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
+                        out[((((size_t)t * ksteps + ks) * 16 + tile) * 64 + l) * 8 + j] = E::from_float(v);
+                    }
+    return SZ_OK;
+}
+template <class E> static int pack_head16_impl(const float* w_in, uint16_t* out) {
+    if (!w_in || !out) return SZ_ERR_INVALID;
+    for (int ks = 0; ks < 8; ks++)
+        for (int tile = 0; tile < 5; tile++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
+                    float v = co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f;
+                    out[(((size_t)ks * 5 + tile) * 64 + l) * 8 + j] = E::from_float(v);
+                }
+    return SZ_OK;
+}
+
 extern "C" {
 
 // Fused conv (+folded BN) + bias (+ residual) (+ ReLU), NHWC bf16, C_out = 256.
@@ -1142,20 +1176,11 @@ int sz_nn_block_bf16(const void* in, const void* w1_packed, const float* bias1, 
 // Weight packing for the 16x16x32 path: [taps][cin/32 k-steps][16 co tiles][64 lanes][8] bf16;
 //   lane l, elem j <- w[co = tile*16 + (l&15)][ci = kstep*32 + 8*(l>>4) + j]
 int sz_nn_pack_weights16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out) {
-    if (!w_in || !out || (ksize != 1 && ksize != 3) || cin_padded % 32 || cin_real > cin_padded) return SZ_ERR_INVALID;
-    const int taps = ksize * ksize, ksteps = cin_padded / 32;
-    for (int t = 0; t < taps; t++)
-        for (int ks = 0; ks < ksteps; ks++)
-            for (int tile = 0; tile < 16; tile++)
-                for (int l = 0; l < 64; l++)
-                    for (int j = 0; j < 8; j++) {
-                        int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
-                        float v = (ci < cin_real) ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
-                        uint32_t u; memcpy(&u, &v, 4);
-                        uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
-                        out[((((size_t)t * ksteps + ks) * 16 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
-                    }
-    return SZ_OK;
+    return pack_weights16_impl<ElemBF16>(w_in, cin_real, cin_padded, ksize, out);
+}
+// the same fragment order with f16 elements (SZ_NN_F16 kernels)
+int sz_nn_pack_weights16_f16(const float* w_in, int32_t cin_real, int32_t cin_padded, int32_t ksize, uint16_t* out) {
+    return pack_weights16_impl<ElemF16>(w_in, cin_real, cin_padded, ksize, out);
 }
 
 // diagnostic: device buffer of 8 u64 per wave (256 workgroups x 4 waves) that receives the phase stamps of the STAMP build; NULL = off
@@ -1185,6 +1210,8 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
@@ -1202,7 +1229,11 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         }
     }
 #define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
-    if (!g_tower_stamps) TOWER_LAUNCH(0);
+    if ((flags & SZ_NN_F16) && g_tower_stamps)
+        hipLaunchKernelGGL((k_tower16_bf16<1, ElemF16>), grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
+    else if (flags & SZ_NN_F16)
+        hipLaunchKernelGGL((k_tower16_bf16<0, ElemF16>), grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
+    else if (!g_tower_stamps) TOWER_LAUNCH(0);
     else if (g_tower_mode == 2) TOWER_LAUNCH(2);
     else if (g_tower_mode == 3) TOWER_LAUNCH(3);
     else if (g_tower_mode == 4) TOWER_LAUNCH(4);
@@ -1280,13 +1311,18 @@ int sz_nn_heads_bf16(const void* x, const void* w_p1_packed, const float* b_p1, 
     static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16<ElemBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        HIPCHK(hipFuncSetAttribute((const void*)k_heads16_bf16<ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
         HIPCHK(hipFuncSetAttribute((const void*)k_value_head<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
         HIPCHK(hipFuncSetAttribute((const void*)k_value_head<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_heads16_bf16, dim3((n_boards + 1) / 2), dim3(256), lds_h, (hipStream_t)stream, (const uint16_t*)x, (const uint4*)w_p1_packed, b_p1,
-                       (const uint4*)w_p2_packed, b_p2, wv, bv, probs, v1_scratch, n_boards, do_softmax);
+    if (do_softmax & SZ_NN_F16)
+        hipLaunchKernelGGL(k_heads16_bf16<ElemF16>, dim3((n_boards + 1) / 2), dim3(256), lds_h, (hipStream_t)stream, (const uint16_t*)x, (const uint4*)w_p1_packed, b_p1,
+                           (const uint4*)w_p2_packed, b_p2, wv, bv, probs, v1_scratch, n_boards, do_softmax & 1);
+    else
+        hipLaunchKernelGGL(k_heads16_bf16<ElemBF16>, dim3((n_boards + 1) / 2), dim3(256), lds_h, (hipStream_t)stream, (const uint16_t*)x, (const uint4*)w_p1_packed, b_p1,
+                           (const uint4*)w_p2_packed, b_p2, wv, bv, probs, v1_scratch, n_boards, do_softmax & 1);
     HIPCHK(hipGetLastError());
     if (n_boards > 2048)
         hipLaunchKernelGGL(k_value_head<4>, dim3((n_boards + 15) / 16), dim3(256), lds_v, (hipStream_t)stream, (const uint16_t*)x, wv, bv, fc1_w_t, fc1_b, fc2_w, fc2_b,
@@ -1320,20 +1356,8 @@ int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, c
     return SZ_OK;
 }
 // host: conv_p2.weight [73][256] f32 -> [8 k32-steps][5 co tiles][64 lanes][8] bf16 (channels 73..79 zero)
-int sz_nn_pack_head16(const float* w_in, uint16_t* out) {
-    if (!w_in || !out) return SZ_ERR_INVALID;
-    for (int ks = 0; ks < 8; ks++)
-        for (int tile = 0; tile < 5; tile++)
-            for (int l = 0; l < 64; l++)
-                for (int j = 0; j < 8; j++) {
-                    int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + j;
-                    float v = co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f;
-                    uint32_t u; memcpy(&u, &v, 4);
-                    uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
-                    out[(((size_t)ks * 5 + tile) * 64 + l) * 8 + j] = (uint16_t)(r >> 16);
-                }
-    return SZ_OK;
-}
+int sz_nn_pack_head16(const float* w_in, uint16_t* out) { return pack_head16_impl<ElemBF16>(w_in, out); }
+int sz_nn_pack_head16_f16(const float* w_in, uint16_t* out) { return pack_head16_impl<ElemF16>(w_in, out); }
 
 // Host-side weight packing into MFMA A-fragment order.
 //   w_in : [256 co][cin_real][k][k] f32 (torch conv weight, BN already folded by the caller)

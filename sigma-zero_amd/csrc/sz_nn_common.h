@@ -48,6 +48,30 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t x) {
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
 
+// ---- operand element of the 16x16x32 MFMA path: bf16 (8 bits of mantissa, f32's range) or f16 (11 bits, range 6e-5 .. 65504: post-BatchNorm
+// activations and BatchNorm-folded weights are O(1), comfortably inside).  Same MFMA cycles, same LDS / weight bytes, one pack instruction per pair either
+// way (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, both round to nearest even), two to expand a pair; ReLU on the packed pair is v_pk_max_i16 for both (sign bit).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+struct ElemBF16 {
+    static constexpr uint32_t ONE = 0x3F80u;
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ float lo(uint32_t v) { return bf16_lo(v); }
+    static __device__ __forceinline__ float hi(uint32_t v) { return bf16_hi(v); }
+    static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static uint16_t from_float(float v) { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }      // host, RNE (finite input)
+};
+struct ElemF16 {
+    static constexpr uint32_t ONE = 0x3C00u;
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2)); }
+    static __device__ __forceinline__ float lo(uint32_t v) { return (float)__builtin_bit_cast(f16x2, v)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t v) { return (float)__builtin_bit_cast(f16x2, v)[1]; }
+    static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static uint16_t from_float(float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; }                          // host, RNE
+};
+
 // ---- stage WGB boards' activations (NHWC rows of C_in bf16) into LDS, plus one zero row ---------------------
 template <int CIN, int WGB, int PAD = 16, bool NT = false>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards, bool skip) {
@@ -76,8 +100,8 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
 
 // ---- stage WGB boards from the engine's bit-packed planes (SZ_PLANES_NHWC128_BITS: 1 KiB per board) ----------
 // uint4 l of a board (l = psub*16 + cq): byte q = channels cq*8..cq*8+7 of position q*4 + psub.  Two threads share a
-// uint4 (q 0..7 / 8..15); each expands 8 bytes to 8 chunks of 8 bf16 (1.0 = 0x3F80) and writes them to its LDS rows.
-template <int WGB, int PAD>
+// uint4 (q 0..7 / 8..15); each expands 8 bytes to 8 chunks of 8 elements (1.0 = E::ONE) and writes them to its LDS rows.
+template <int WGB, int PAD, class E = ElemBF16>
 __device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards) {
     constexpr int PITCH = 128 * 2 + PAD;
     const uint4* src = (const uint4*)in + (size_t)board0 * 64;
@@ -89,10 +113,10 @@ __device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16
         for (int qq = 0; qq < 8; qq++) {
             const uint32_t byte = ((qq < 4 ? w0 : w1) >> ((qq & 3) * 8)) & 0xFFu;
             uint4 o;
-            o.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
-            o.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
-            o.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
-            o.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+            o.x = ((byte & 1) ? E::ONE : 0u) | ((byte & 2) ? (E::ONE << 16) : 0u);
+            o.y = ((byte & 4) ? E::ONE : 0u) | ((byte & 8) ? (E::ONE << 16) : 0u);
+            o.z = ((byte & 16) ? E::ONE : 0u) | ((byte & 32) ? (E::ONE << 16) : 0u);
+            o.w = ((byte & 64) ? E::ONE : 0u) | ((byte & 128) ? (E::ONE << 16) : 0u);
             const int pos = (half * 8 + qq) * 4 + psub;
             *(uint4*)(lds + (board * 64 + pos) * PITCH + cq * 16) = o;
         }

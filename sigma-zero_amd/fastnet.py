@@ -25,21 +25,29 @@ def _fold_bn(conv_w, bn, conv_b=None):
     return w.float(), b.float()
 
 
-def _pack(w, cin_padded, ksize, device, w16=False):
-    """[256, cin, k, k] f32 -> MFMA A-fragment order (uint16 bf16 bits) on `device`.
+def _pack(w, cin_padded, ksize, device, w16=False, f16=False):
+    """[256, cin, k, k] f32 -> MFMA A-fragment order (uint16 bf16 bits; f16 bits with f16=True) on `device`.
     w16: fragment order of the 16x16x32 kernels (sz_nn_pack_weights16) instead of the 32x32x16 ones."""
     w = w.contiguous().cpu().float().numpy()
     co, cin = w.shape[0], w.shape[1]
-    assert co == 256
+    assert co == 256 and (w16 or not f16)
     out = np.zeros(ksize * ksize * cin_padded * 256, dtype=np.uint16)
-    fn = N.lib().sz_nn_pack_weights16 if w16 else N.lib().sz_nn_pack_weights
+    fn = (N.lib().sz_nn_pack_weights16_f16 if f16 else N.lib().sz_nn_pack_weights16) if w16 else N.lib().sz_nn_pack_weights
     N.check(fn(w.ctypes.data_as(C.c_void_p), cin, cin_padded, ksize, out.ctypes.data_as(C.c_void_p)), "sz_nn_pack_weights")
     return torch.from_numpy(out.view(np.int16)).to(device)
 
 
 class FastPolicyNet:
-    def __init__(self, model, device=None, mfma16=True):
+    """operands: "bf16" (default) or "fp16" — the element type of the MFMA operands (weights and stored activations; accumulation, bias,
+    residual add and the value MLP are f32 either way).  fp16 keeps 11 bits of mantissa instead of 8 at the same speed; it needs the
+    16x16x32 kernels with the persistent tower and the fused heads (the defaults)."""
+
+    def __init__(self, model, device=None, mfma16=True, operands="bf16"):
         model = model.eval()
+        assert operands in ("bf16", "fp16") and (operands == "bf16" or mfma16)
+        self.operands = operands
+        self.f16 = operands == "fp16"
+        self.eflag = N.SZ_NN_F16 if self.f16 else 0
         if device is None:                   # the GPU the fp32 module lives on, else this process's current device (never a silent cuda:0)
             pdev = next(model.parameters()).device
             device = pdev if pdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
@@ -51,7 +59,7 @@ class FastPolicyNet:
         self.flag = N.SZ_NN_W16 if self.w16 else 0
         pack_fn = _pack
         def _pack_w(w, cin_padded, ksize, device):
-            return pack_fn(w, cin_padded, ksize, device, w16=self.w16)
+            return pack_fn(w, cin_padded, ksize, device, w16=self.w16, f16=self.f16)
         self.layers = []          # (packed_w, bias, cin, ksize)
         w, b = _fold_bn(model.conv1.weight, model.norm_layer)
         self.stem = (_pack_w(w, 128, 3, dev), b.to(dev).contiguous())
@@ -75,7 +83,7 @@ class FastPolicyNet:
         # native heads (csrc/sz_nn.hip k_policy_head / k_value_head): packed conv_p2, folded conv_v1, fc weights in f32
         wp2 = model.conv_p2.weight.detach().view(73, 256).contiguous().cpu().float().numpy()
         packed = np.zeros(8 * 5 * 64 * 8, dtype=np.uint16)
-        N.check(N.lib().sz_nn_pack_head16(wp2.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "sz_nn_pack_head16")
+        N.check((N.lib().sz_nn_pack_head16_f16 if self.f16 else N.lib().sz_nn_pack_head16)(wp2.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "sz_nn_pack_head16")
         self.wp2_packed = torch.from_numpy(packed.view(np.int16)).to(dev)
         self.wv_f32 = wv.view(256).contiguous().to(dev)
         self.bv_f = float(bv.view(-1)[0])
@@ -140,6 +148,8 @@ class FastPolicyNet:
         B = planes.shape[0]
         a, t, c = self._buffers(B)[:3]
         in_bits = N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0      # engine planes_dtype="bits128" (1 KiB per board)
+        if self.f16 and planes.dtype == torch.bfloat16:
+            planes = planes.to(torch.float16)            # the engine's "nhwc128" image is bf16; the f16 kernels read f16 (the default bit-packed image needs no conversion)
         if in_bits and not self.w16:
             raise ValueError("bit-packed planes need the 16x16x32 kernels (mfma16=True)")
         if self.persistent_tower and (B <= self.persistent_max_boards):
@@ -147,12 +157,14 @@ class FastPolicyNet:
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B, in_bits,
+            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B, in_bits | self.eflag,
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_bf16")
             if ev is not None:
                 ev[1].record()
                 self.timing.append(ev)
             return a, t
+        if self.f16:
+            raise ValueError("fp16 operands need the persistent tower")
         self._conv(planes, self.stem[0], self.stem[1], None, a, B, 128, 3, relu=1 | in_bits)
         for (w1, b1, w2, b2) in self.blocks:
             if self.fuse_blocks:
@@ -194,8 +206,10 @@ class FastPolicyNet:
                 P = lambda t: C.c_void_p(t.data_ptr())
                 N.check(N.lib().sz_nn_heads_bf16(P(x), P(self.p1[0]), P(self.p1[1]), P(self.wp2_packed), P(self.bp2), P(self.wv_f32), self.bv_f,
                                                  P(self.fc1_w), P(self.fc1_b), P(self.fc2_w_vec), self.fc2_b_f, P(policy), P(value), P(v1),
-                                                 B, int(bool(inference)), st), "sz_nn_heads_bf16")
+                                                 B, int(bool(inference)) | self.eflag, st), "sz_nn_heads_bf16")
                 return policy, value.view(B, 1)
+            if self.f16:
+                raise ValueError("fp16 operands need the fused heads")
             self._conv(x, self.p1[0], self.p1[1], None, scratch, B, 256, 1)
             N.check(N.lib().sz_nn_policy_head_bf16(C.c_void_p(scratch.data_ptr()), C.c_void_p(self.wp2_packed.data_ptr()), C.c_void_p(self.bp2.data_ptr()),
                                                    C.c_void_p(policy.data_ptr()), B, int(bool(inference)), st), "sz_nn_policy_head_bf16")

@@ -259,9 +259,15 @@ def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
 
 def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True):
     """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training.
-    fast_inference: True / "bf16" = FastPolicyNet (bf16 MFMA tower, the throughput configuration); "split" = SplitPolicyNet (hi+lo bf16
-    operands on the matrix cores: the reference's precision class, reproduces the fp32 network's search results, ~1/3 of the bf16 speed);
-    False / "fp32" = the torch module itself."""
+    fast_inference — the self-play network, fastest first (measured on MI355X at 4096 boards x 800 searches; fidelity = the same 64 positions
+    searched with the fp32 module, tests/test_gpu_train_and_precision.py):
+      "bf16"          FastPolicyNet on bf16 operands: the throughput configuration BASELINE.json names (1.00x); 61-62 of 64 boards with the fp32
+                      network's exact visit counts, the others differ by one visit (max |delta fraction| 1.3e-3 at 800 searches);
+      True / "fp16"   THE DEFAULT: the same kernels on f16 operands (11 bits of mantissa instead of 8; same cycles, the chip holds a 5 % lower
+                      clock): 0.95x, 64 of 64 boards with the fp32 network's exact visit counts at 100 and at 800 searches;
+      "split"         SplitPolicyNet (hi + lo bf16 operands, 3 MFMAs per product): the reference's precision class by construction (logits
+                      within 6e-6 of fp64, fp32 itself is at 4e-7), 0.40x; reproduces the reference's own CPU game ply for ply;
+      False / "fp32"  the torch module itself (MIOpen), 0.04x."""
     from .sim import play_games
     from .fastnet import FastPolicyNet, SplitPolicyNet
     device = next(model.parameters()).device
@@ -270,8 +276,12 @@ def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync
         player = model
     elif fast_inference == "split":
         player = SplitPolicyNet(model, device=device)
-    else:
+    elif fast_inference == "bf16":
         player = FastPolicyNet(model, device=device)
+    elif fast_inference in (True, "fp16"):
+        player = FastPolicyNet(model, device=device, operands="fp16")
+    else:
+        raise ValueError("fast_inference: %r" % (fast_inference,))
     games = play_games(player, args, n_games, c960=chess960, max_plies=args.get("max_plies", 100000))
     packed, aidx, aprob, rew = records_from_games(games)
     dl = DeviceBatches(packed, aidx, aprob, rew, batch_size=batch_size, device=device, shuffle=True)       # same batches as DataLoader + collate
@@ -325,8 +335,9 @@ def main(argv=None):
     ap.add_argument("--save-dir", default="saves")
     ap.add_argument("--games-dir", default="games")
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--inference", default="bf16", choices=["bf16", "split", "fp32"],
-                    help="self-play network: bf16 MFMA tower (fast), split = hi+lo bf16 operands on the matrix cores (fp32-class results), fp32 = torch module")
+    ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split", "fp32"],
+                    help="self-play network (run_cycle): fp16 = MFMA tower on f16 operands (default: fp32's visit counts on every tested position, 0.95x of bf16), "
+                         "bf16 = fastest (single visits move), split = hi+lo bf16 operands (fp32-class by construction, 0.40x), fp32 = torch module")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     gpr = [int(x) for x in str(a.games_per_rank).split(",")]

@@ -224,6 +224,34 @@ def test_fused_heads_match_separate_head_kernels():
             assert float((v0 - v1).abs().max()) < 1e-5, float((v0 - v1).abs().max())
 
 
+def test_fp16_operand_network_matches_fp32_policynn():
+    """FastPolicyNet(operands="fp16"): the persistent tower and the fused heads on f16 MFMA operands (11 bits of mantissa; accumulation, bias, residual add in
+    f32) against the fp32 module.  Measured on MI355X: tower activation 7.3e-4, centred logits 6.4e-4 relative L2 from fp64 (bf16 operands: 5.8e-3 / 5.1e-3)."""
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.05); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.05)
+    f16, b16 = FastPolicyNet(net, operands="fp16"), FastPolicyNet(net)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    c = lambda t: t - t.mean(1, keepdim=True)
+    for B in (1, 37, 600):
+        x = (torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
+        with torch.no_grad():
+            p_ref, v_ref = net(x, inference=False)
+            y_ref = net.resnet_blocks(torch.relu(net.norm_layer(net.conv1(x))))
+            p, v = (t.clone() for t in f16(planes_nchw_to_nhwc128(x), inference=False))
+            pb, vb = (t.clone() for t in b16(planes_nchw_to_nhwc128(x), inference=False))
+            y = f16.tower(planes_nchw_to_nhwc128(x))[0].view(torch.float16).float().view(B, 8, 8, 256).permute(0, 3, 1, 2)
+            pi, _ = (t.clone() for t in f16(planes_nchw_to_nhwc128(x), inference=True))
+            pi_ref, _ = net(x, inference=True)
+        e16, eb = float((c(p) - c(p_ref)).norm() / c(p_ref).norm()), float((c(pb) - c(p_ref)).norm() / c(p_ref).norm())
+        assert float((y - y_ref).norm() / y_ref.norm()) < 3e-3 and e16 < 3e-3 and e16 < eb / 3, (e16, eb)       # and at least 3x closer than bf16 operands
+        assert float((v.view(-1) - v_ref.view(-1)).abs().max()) < 5e-3
+        assert torch.allclose(pi.sum(1), torch.ones(B, device="cuda"), atol=1e-5) and float((pi.log() - pi_ref.log()).abs().max()) < 5e-3
+
+
 def test_split_precision_network_matches_fp32_policynn():
     """SplitPolicyNet (k_tower_split: hi + lo bf16 operands, three MFMAs per product, f32 accumulation, f32 heads) against the fp32 module —
     the reference's precision class (network.py has no reduced precision anywhere).  Tolerances are ~5x what was measured on MI355X

@@ -90,14 +90,14 @@ def _root_distributions(model, positions, S, planes_dtype):
     return action, visits, n_child
 
 
-@pytest.mark.parametrize("S", [100, 800])
-def test_bf16_network_search_divergence_from_fp32(S):
-    """The shipped inference path (FastPolicyNet: bf16 MFMA tower) against the reference-precision network (fp32 policyNN) on the SAME
-    64 positions: legal-move sets and child order are identical by construction; what moves is the visit distribution.  The figures are
+@pytest.mark.parametrize("operands,S", [("bf16", 100), ("bf16", 800), ("fp16", 100), ("fp16", 800)])
+def test_bf16_network_search_divergence_from_fp32(operands, S):
+    """The fast inference path (FastPolicyNet: MFMA tower on bf16 or fp16 operands) against the reference-precision network (fp32 policyNN) on the
+    SAME 64 positions: legal-move sets and child order are identical by construction; what moves is the visit distribution.  The figures are
     printed (and quoted in DESIGN.md §4); the bounds below are what the random-init network gives with margin."""
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
-    fast = FastPolicyNet(net)
+    fast = FastPolicyNet(net, operands=operands)
     pos = _positions(64, seed=S)
     a32, v32, n32 = _root_distributions(net, pos, S, torch.float32)
     a16, v16, n16 = _root_distributions(fast, pos, S, "bits128")
@@ -112,11 +112,12 @@ def test_bf16_network_search_divergence_from_fp32(S):
         eps = 1e-9
         kl.append(float(np.sum(p * np.log((p + eps) / (q + eps)))))
         top_share.append(float(q[np.argmax(p)] / max(p.max(), eps)))           # how much of fp32's favourite's visits bf16 gives that move
-    rep = dict(S=S, boards=len(pos), top_move_agreement=float(np.mean(top_same)), mean_L1=float(np.mean(l1)), max_Linf=float(np.max(linf)),
+    rep = dict(operands=operands, S=S, boards=len(pos), identical_boards=int(sum(int(np.array_equal(v32[b, :int(n32[b])], v16[b, :int(n32[b])])) for b in range(len(pos)))),
+               top_move_agreement=float(np.mean(top_same)), mean_L1=float(np.mean(l1)), max_Linf=float(np.max(linf)),
                mean_Linf=float(np.mean(linf)), mean_KL=float(np.mean(kl)), max_KL=float(np.max(kl)), favourite_share=float(np.mean(top_share)))
-    print("bf16-vs-fp32 search divergence:", json.dumps(rep))
+    print("%s-vs-fp32 search divergence:" % operands, json.dumps(rep))
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "bf16_vs_fp32_search_S%d.json" % S), "w") as f:
+    with open(os.path.join("gpurun_out", "%s_vs_fp32_search_S%d.json" % (operands, S)), "w") as f:
         json.dump(rep, f)
     # not within the north star's 1e-4 (that tolerance is met by the fp32 path: tests/test_gpu_parity.py, test_gpu_reference_golden.py);
     # bounded so that a regression of the bf16 kernels shows up here

@@ -7,8 +7,9 @@ import sigma_zero_amd as sz
 from sigma_zero_amd import _native as N
 from sigma_zero_amd.fastnet import FastPolicyNet, planes_nchw_to_nhwc128
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+OPERANDS = os.environ.get("SZ_OPERANDS", "bf16")          # SZ_OPERANDS=fp16: the f16-operand tower (mode 1 only)
 torch.manual_seed(0)
-fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+fast = FastPolicyNet(sz.policyNN({}).cuda().eval(), operands=OPERANDS)
 fast.persistent_max_boards = 1 << 30
 planes = planes_nchw_to_nhwc128((torch.rand(B, 119, 8, 8, device="cuda") < 0.12).float())
 t_end = time.time() + 2.0
@@ -34,3 +35,9 @@ for mode in modes:
     tot = s[:, 6] - s[:, 0]
     mf = 2 * 36864 * (1.0 if mode == 5 else 66.0 / 72.0)
     print("  block total median %.0f cycles; MFMA-busy fraction %.3f (%.0f MFMA cycles per block)" % (np.median(tot), mf / np.median(tot), mf))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fast.tower(planes)
+    e1.record(); torch.cuda.synchronize()
+    print("  operands %s: %.3f ms per launch of the shipped kernel (same process, right after)" % (OPERANDS, e0.elapsed_time(e1) / 10))
