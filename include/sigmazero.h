@@ -142,7 +142,8 @@ int sz_fetch_ply(sz_engine* e, uint8_t* packed_planes, int32_t* action, int32_t*
 /* NON-REFERENCE option, off by default: true AlphaZero root noise.  gamma_dev: device array [n_boards][SZ_MAX_MOVES]
  * f32 of Gamma(alpha,1) draws, read when a search's ROOT is expanded (the step after sz_search_begin): root prior k becomes
  * 0.75*p_k + 0.25*g_k/sum_{j<K} g_j (one Dirichlet(alpha) sample over the K legal moves); inner nodes get no noise.  NULL restores
- * the reference behaviour (mcts.py:91-98: the constant noise_value at every expansion).  Needs learning = 1. */
+ * the reference behaviour (mcts.py:91-98: the constant noise_value at every expansion).  Needs learning = 1.  Refused (SZ_ERR_STATE) on an engine created
+ * with reuse_subtree: a reused root is never expanded again, the noise would silently reach the first ply of a game only. */
 int sz_set_root_noise(sz_engine* e, const float* gamma_dev);
 
 /* diagnostic only: with a device buffer of n_boards*8 uint64, sz_search_step records s_memtime at its phase boundaries per board

@@ -926,6 +926,7 @@ int sz_new_games(sz_engine* e, const int32_t* scharnagl, const uint8_t* active, 
 
 int sz_debug_step_stamps(sz_engine* e, void* dev_buffer) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
     e->v.dbg = (unsigned long long*)dev_buffer;
     return SZ_OK;
 }
@@ -947,6 +948,10 @@ int sz_compact(sz_engine* e, int32_t enable, int32_t* n_live_out, void* stream) 
 
 int sz_set_root_noise(sz_engine* e, const float* gamma_dev) {
     if (!e) return SZ_ERR_INVALID;
+    ENGINE_GUARD(e);
+    // a reused root (sz_config.reuse_subtree) was expanded as an inner node, on un-noised priors, and is never expanded again: root noise would silently
+    // apply to the first ply of a game only.  The two non-reference options are therefore mutually exclusive.
+    if (gamma_dev && e->v.reuse) return SZ_ERR_STATE;
     e->v.root_gamma = gamma_dev;
     return SZ_OK;
 }

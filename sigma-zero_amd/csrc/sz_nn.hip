@@ -1216,7 +1216,9 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     }
     const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
     const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
-    {   // XCD-paced tile rounds (see the kernel); SZ_NN_PACE=0 switches them off
+    unsigned long long pace_add = 0, *pace_slot = nullptr;     // the arrival counters advance only when the launch went out (a failed launch leaves them consistent)
+    {   // XCD-paced tile rounds (see the kernel); SZ_NN_PACE=0 switches them off.  The counters are per device and not thread-safe: one engine thread per GPU
+        // (the C ABI's contract); a wrong base costs a bounded wait, never a wrong result.
         static int pace_on = -1;
         static unsigned long long* pace_buf[NN_MAX_DEVICES] = {};
         static unsigned long long pace_total[NN_MAX_DEVICES] = {};
@@ -1225,7 +1227,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
             const int slot = current_device_slot();
             if (!pace_buf[slot]) { HIPCHK(hipMalloc(&pace_buf[slot], 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(pace_buf[slot], 0, 8 * sizeof(unsigned long long))); }
             prm.pace = pace_buf[slot]; prm.pace_base = pace_total[slot];
-            pace_total[slot] += (unsigned long long)(n_tiles / (int)grid.x) * (grid.x / 8);
+            pace_add = (unsigned long long)(n_tiles / (int)grid.x) * (grid.x / 8); pace_slot = &pace_total[slot];
         }
     }
 #define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
@@ -1241,6 +1243,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     else TOWER_LAUNCH(1);
 #undef TOWER_LAUNCH
     HIPCHK(hipGetLastError());
+    if (pace_slot) *pace_slot += pace_add;
     return SZ_OK;
 }
 

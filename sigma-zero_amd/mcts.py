@@ -48,8 +48,10 @@ class MCTS0:
         eng.check_errors()
         action, visits, n_child, prior, wsum = eng.root_children()
         k = int(n_child[0])
-        self._tree = eng.debug_tree(0)
-        self._root_game = self.game.copy()                    # the view is built lazily; the caller may have moved self.game by then (sim.py:76)
+        # the Node view is built lazily (`.root`): the whole-tree readback costs more than a small search and most callers only want the dict
+        # (sim.py:63-68, eval.py:92-94).  The engines are this object's own, so the tree stays in HBM untouched until its next search.
+        self._tree, self._tree_engine = None, eng
+        self._root_game = self.game.copy()                    # the caller may have moved self.game by the time the view is asked for (sim.py:76)
         self._root = None
         total = int(visits[0, :k].sum())
         if k and total == 0:
@@ -59,7 +61,9 @@ class MCTS0:
     @property
     def root(self):
         """The finished tree as reference-style Node objects (mctsnode.py:7-18 fields), built on first access from the engine's store."""
-        if self._root is None and self._tree is not None:
+        if self._root is None and getattr(self, "_tree_engine", None) is not None:
+            if self._tree is None:
+                self._tree = self._tree_engine.debug_tree(0)
             self._root = Node.from_engine_tree(self._root_game, self.args, self._tree)
         return self._root
 

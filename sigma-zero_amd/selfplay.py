@@ -73,6 +73,9 @@ class SelfPlayEngine:
         # NON-REFERENCE option (default off): args["root_dirichlet_alpha"] = alpha switches from the reference's noise (the constant
         # 1-2^-24 at every expansion, mcts.py:91-98) to AlphaZero's Dirichlet(alpha) noise on the root's children only
         self.root_alpha = self.args.get("root_dirichlet_alpha")
+        if self.root_alpha is not None and self.args.get("reuse_subtree", False):
+            raise ValueError("args['root_dirichlet_alpha'] and args['reuse_subtree'] exclude each other: a reused root was expanded as an inner node "
+                             "(un-noised priors) and is never expanded again, so the root noise would reach the first ply of a game only")
         self._gamma = None
 
     def close(self):

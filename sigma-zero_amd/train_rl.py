@@ -316,6 +316,36 @@ def pack_games_for_save(games):
             "rewards": rew, "colours": [c for g in games for c in g["colours"]]}
 
 
+def merge_game_files(games_dir, epoch, world):
+    """train_RL.py:229-241 merges every worker's games into ONE games/RL_960_{epoch}.pt.  Here every rank writes its own file; this concatenates
+    them key-wise (rank order) into the reference's file name and removes the per-rank files.  Meant for small runs: at 8 x 4096 games per cycle
+    the merged pickle is several GB through one process (`--merge-games`, off by default)."""
+    base = os.path.join(games_dir, "RL_960_%d.pt" % epoch)
+    merged = torch.load(base, weights_only=True)
+    for r in range(1, world):
+        part_path = os.path.join(games_dir, "RL_960_%d.rank%d.pt" % (epoch, r))
+        part = torch.load(part_path, weights_only=True)
+        for k in ("states", "actions", "rewards", "colours"):
+            merged[k] = list(merged[k]) + list(part[k])
+        os.remove(part_path)
+    torch.save(merged, base)
+    return len(merged["rewards"])
+
+
+def write_step_log(path, epoch, hist, lr_scheduler, append=True):
+    """One JSON line per optimiser step (train_RL.py:124-125 logs loss, mse and cross-entropy per step): written after the passes from the
+    device-side history, so that logging costs no host synchronisation inside the training loop."""
+    import json
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    first = (lr_scheduler.last_epoch - len(hist)) if lr_scheduler is not None else 0
+    with open(path, "a" if append else "w") as f:
+        for i, (mse, ce) in enumerate(hist):
+            rec = {"epoch": epoch, "step": first + i, "loss": mse + ce, "mse": mse, "cross_entropy": ce}
+            if lr_scheduler is not None:
+                rec["lr"] = lr_scheduler.base_lrs[0] * lr_scheduler.gamma ** ((first + i) // lr_scheduler.step_size)
+            f.write(json.dumps(rec) + "\n")
+
+
 def main(argv=None):
     """`python -m torch.distributed.run --nproc-per-node N -m sigma_zero_amd.train_rl ...` (or plain python for one GPU):
     every rank self-plays its own games on its own GPU (no communication), then all ranks train with averaged gradients."""
@@ -335,6 +365,8 @@ def main(argv=None):
     ap.add_argument("--save-dir", default="saves")
     ap.add_argument("--games-dir", default="games")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--log-dir", default="logs", help="per-step loss log logs/RL_train.jsonl (rank 0); empty string = off")
+    ap.add_argument("--merge-games", action="store_true", help="concatenate the ranks' game files into the reference's single games/RL_960_{epoch}.pt (small runs)")
     ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split", "fp32"],
                     help="self-play network (run_cycle): fp16 = MFMA tower on f16 operands (default: fp32's visit counts on every tested position, 0.95x of bf16), "
                          "bf16 = fastest (single visits move), split = hi+lo bf16 operands (fp32-class by construction, 0.40x), fp32 = torch module")
@@ -380,8 +412,15 @@ def main(argv=None):
         # concatenation — not done here: at 8 x 4096 games per cycle the merged pickle would be several GB through one process)
         os.makedirs(a.games_dir, exist_ok=True)
         torch.save(pack_games_for_save(games), os.path.join(a.games_dir, ("RL_960_%d.pt" % epoch) if rank == 0 else ("RL_960_%d.rank%d.pt" % (epoch, rank))))
+        if a.merge_games and world > 1:
+            dist.barrier()                                               # every rank's file is on disk
+            if rank == 0:
+                n_all = merge_game_files(a.games_dir, epoch, world)
+                print("epoch %d: merged %d samples of %d ranks into %s" % (epoch, n_all, world, os.path.join(a.games_dir, "RL_960_%d.pt" % epoch)), flush=True)
         if rank == 0:
             save_cycle(model, optimiser, epoch, a.save_dir)
+            if a.log_dir:
+                write_step_log(os.path.join(a.log_dir, "RL_train.jsonl"), epoch, hist, sched)
             last = hist[-1] if hist else (float("nan"), float("nan"))
             print("epoch %d: %d ranks x %d games, %d samples on rank 0, %d optimiser steps, last mse %.4f ce %.4f"
                   % (epoch, world, a.games_per_rank, n_samples, len(hist), last[0], last[1]), flush=True)

@@ -440,9 +440,13 @@ def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, PYTHONPATH=root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
            os.path.join(root, "tools", "run_train_rl.py"), "--epochs", "1", "--games-per-rank", "6,9", "--searches", "4", "--batch-size", "8", "--total-steps", "0",
-           "--max-plies", "10", "--backend", "gloo", "--save-dir", str(tmp_path / "saves"), "--games-dir", str(tmp_path / "games")]
+           "--max-plies", "10", "--backend", "gloo", "--save-dir", str(tmp_path / "saves"), "--games-dir", str(tmp_path / "games"), "--log-dir", str(tmp_path / "logs")]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    # per-step loss log (train_RL.py:124-125): one JSON line per optimiser step
+    import json
+    steps = [json.loads(l) for l in open(tmp_path / "logs" / "RL_train.jsonl")]
+    assert len(steps) == 7 and [r["step"] for r in steps] == list(range(7)) and all(np.isfinite(r["loss"]) and abs(r["loss"] - r["mse"] - r["cross_entropy"]) < 1e-6 and r["lr"] == 1e-4 for r in steps)
     # rank 0 holds 60 samples = 7 batches of 8, rank 1 holds 90 = 11: both run MIN = 7 all-reduced steps (no deadlock)
     assert "epoch 1: 2 ranks x 6 games" in out.stdout and "7 optimiser steps" in out.stdout
     other = torch.load(tmp_path / "games" / "RL_960_1.rank1.pt", weights_only=True)
@@ -452,6 +456,14 @@ def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
     games = torch.load(tmp_path / "games" / "RL_960_1.pt", weights_only=True)
     assert len(games["states"]) == len(games["actions"]) == len(games["rewards"]) == len(games["colours"]) > 0
     assert tuple(games["states"][0].shape) == (119, 8) and games["states"][0].dtype == torch.uint8
+    # --merge-games: the reference's single games file (train_RL.py:229-241) = rank 0's samples followed by rank 1's
+    out = subprocess.run([("29534" if c == "29533" else c) for c in cmd] + ["--merge-games", "--games-dir", str(tmp_path / "games2"), "--save-dir", str(tmp_path / "saves2"), "--log-dir", ""],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    merged = torch.load(tmp_path / "games2" / "RL_960_1.pt", weights_only=True)
+    assert len(merged["states"]) == len(merged["actions"]) == len(merged["rewards"]) == len(merged["colours"]) == 150
+    assert not (tmp_path / "games2" / "RL_960_1.rank1.pt").exists()
+    assert all(torch.equal(a, b) for a, b in zip(merged["states"][:60], games["states"])) and all(torch.equal(a, b) for a, b in zip(merged["states"][60:], other["states"]))
 
 
 def test_slot_refill_keeps_other_boards_intact():

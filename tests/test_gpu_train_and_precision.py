@@ -335,3 +335,15 @@ def test_board_revived_without_recompaction_is_an_error_not_a_silent_skip():
         eng.check_errors()
     assert ei.value.code == N.SZ_ERR_STATE
     eng.close()
+
+
+def test_root_noise_and_subtree_reuse_exclude_each_other():
+    """the two non-reference options cannot be combined (a reused root is never expanded again, so its children would never see the noise): refused at both levels"""
+    with pytest.raises(ValueError):
+        SelfPlayEngine(None, {"C": 2, "num_searches": 8, "reuse_subtree": True, "root_dirichlet_alpha": 0.3}, 2, chess960=True, learning=True)
+    eng = SelfPlayEngine(None, {"C": 2, "num_searches": 8, "reuse_subtree": True}, 2, chess960=True, learning=True)
+    from sigma_zero_amd import _native as N
+    with pytest.raises(N.NativeError):
+        eng.set_root_noise(torch.ones(2, 218, device="cuda"))
+    eng.set_root_noise(None)
+    eng.close()

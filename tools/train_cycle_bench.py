@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sigma_zero_amd as sz
 from sigma_zero_amd import train_rl as T
-from sigma_zero_amd.fastnet import FastPolicyNet
+from sigma_zero_amd.fastnet import FastPolicyNet, SplitPolicyNet
 from sigma_zero_amd.sim import play_games
 
 ap = argparse.ArgumentParser()
@@ -15,6 +15,8 @@ ap.add_argument("--max-plies", type=int, default=40)
 ap.add_argument("--batch-size", type=int, default=128)
 ap.add_argument("--total-steps", type=int, default=6)
 ap.add_argument("--backend", default="nccl")
+ap.add_argument("--slots", type=int, default=0, help="board slots (default: one per game); fewer slots than games = refill + compaction")
+ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split"], help="self-play network (run_cycle's default is fp16)")
 a = ap.parse_args()
 rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -30,10 +32,12 @@ sync = T.GradSync(model) if world > 1 else None
 def sync_t():
     torch.cuda.synchronize(dev); return time.perf_counter()
 t0 = sync_t()
-model.eval(); player = FastPolicyNet(model, device=dev)
+model.eval()
+player = SplitPolicyNet(model, device=dev) if a.inference == "split" else FastPolicyNet(model, device=dev, operands=a.inference)
 t1 = sync_t()
 args = {"C": 2, "num_searches": a.searches}
-games = play_games(player, args, a.games, c960=True, max_plies=a.max_plies)
+st = {}
+games = play_games(player, args, a.games, c960=True, max_plies=a.max_plies, n_boards=a.slots or None, stats=st, verbose=True)
 t2 = sync_t()
 packed, aidx, aprob, rew = T.records_from_games(games)
 dl = T.DeviceBatches(packed, aidx, aprob, rew, batch_size=a.batch_size, device=dev, shuffle=True)
@@ -43,10 +47,13 @@ t4 = sync_t()
 T.sync_module_state(model, average_buffers=True)
 t5 = sync_t()
 plies = sum(len(g["actions"]) for g in games)
-out = {"workload": "train_RL cycle: %d Chess960 games/rank x <=%d plies x %d searches, then %d passes of batch %d (fp32, Adam)" % (a.games, a.max_plies, a.searches, a.total_steps + 1, a.batch_size),
+lens = sorted(len(g["actions"]) for g in games)
+out = {"workload": "train_RL cycle: %d Chess960 games/rank on %d slots x <=%d plies x %d searches (%s self-play network), then %d passes of batch %d (fp32, Adam)"
+                   % (a.games, a.slots or a.games, a.max_plies, a.searches, a.inference, a.total_steps + 1, a.batch_size),
+       "game_plies_min_median_max": [lens[0], lens[len(lens) // 2], lens[-1]], "self_play_work": st,
        "ranks": world, "samples_rank0": plies, "optimiser_steps": len(hist),
        "seconds": {"inference_net_build (BN fold + weight pack)": t1 - t0, "self_play": t2 - t1, "records + dataset": t3 - t2, "train": t4 - t3, "state sync": t5 - t4},
-       "self_play_simulations_per_s": plies * a.searches / (t2 - t1), "train_samples_per_s": len(hist) * a.batch_size / max(t4 - t3, 1e-9),
+       "self_play_simulations_per_s": plies * a.searches / (t2 - t1), "train_share_of_cycle": (t4 - t3) / (t5 - t0), "train_samples_per_s": len(hist) * a.batch_size / max(t4 - t3, 1e-9),
        "train_ms_per_step": 1e3 * (t4 - t3) / max(len(hist), 1), "last_loss": list(hist[-1]) if hist else None}
 if rank == 0:
     print(json.dumps(out))
