@@ -201,8 +201,12 @@ int sz_nn_pack_head16_f16(const float* w_in, uint16_t* out);
  * (sz_nn_pack_weights16 order; [0] = stem packed with cin_padded = 128).
  * The workgroups that share an XCD start their tile rounds together (bounded wait on one arrival counter per XCD, allocated on first use), so a layer's
  * weights cross the fabric once per XCD and round; environment SZ_NN_PACE=0 switches that off.  Results do not depend on it. */
+/* Two boards per workgroup when n_boards exceeds the number of CUs, else one (half the latency of a forward at small batches: a search of one position, the
+ * tail of a self-play run); a board's result does not depend on the form.  SZ_NN_TOWER_WGB1 / _WGB2 force one (tests). */
+#define SZ_NN_TOWER_WGB1 0x10000000
+#define SZ_NN_TOWER_WGB2 0x20000000
 int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const float* const* bias, int32_t n_blocks, void* out,
-                     int32_t n_boards, int32_t flags /* 0 or SZ_NN_IN_BITS */, void* stream);
+                     int32_t n_boards, int32_t flags /* SZ_NN_IN_BITS | SZ_NN_F16 | SZ_NN_TOWER_WGB* */, void* stream);
 /* The same tower at the REFERENCE's precision class (network.py:176-184 is fp32 end to end) on the matrix cores: every operand carried as two bf16
  * numbers (hi = bf16(x), lo = bf16(x - hi): 16 bits of mantissa), every product as three MFMAs (hi*hi + lo*hi + hi*lo) with f32 accumulation, bias /
  * residual / ReLU in f32.  w_stream: ONE device buffer with the weights of the whole tower in k-step order, built on the host with

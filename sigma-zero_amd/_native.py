@@ -12,6 +12,7 @@ SZ_NN_W16 = 0x40000
 SZ_NN_IN_BITS = 0x1000000
 SZ_NN_SPLIT_WGB1, SZ_NN_SPLIT_WGB2 = 0x2000000, 0x4000000
 SZ_NN_F16 = 0x8000000
+SZ_NN_TOWER_WGB1, SZ_NN_TOWER_WGB2 = 0x10000000, 0x20000000
 
 
 class sz_config(C.Structure):

@@ -965,12 +965,14 @@ struct TowerParams {
 // STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
 // a buffer of their own; the shipped instantiation (STAMP = false) executes no stamp.
 #define TSTAMP(k) do { if (STAMP_ && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
-template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 1/2/3 (results garbage) */, class E = ElemBF16 /* operand element: bf16 or f16 */>
+// WGB = 1: ONE board per workgroup, for batches of at most #CUs boards (a search of one position, the tail of a self-play run): half the latency per forward
+// of a 2-board tile with an empty half.  Same accumulation order per output element, so a board's result does not depend on the form.
+template <int MODE /* 0 = shipped; 1 = stamps; 2/3/4 = stamps + K-loop ablation 1/2/3 (results garbage) */, class E = ElemBF16 /* operand element: bf16 or f16 */,
+          int WGB = 2 /* boards per workgroup */>
 __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restrict__ planes, TowerParams prm, uint16_t* __restrict__ out, int n_boards, int n_blocks, int flags,
                                                           unsigned long long* __restrict__ stamps) {
     constexpr bool STAMP_ = MODE != 0;
     constexpr int ABL = MODE == 5 ? 4 : (MODE >= 2 ? MODE - 1 : 0);      // 5: stamps with the border-row skipping switched off (A/B of SKIPROWS)
-    constexpr int WGB = 2;
     constexpr int IMG = WGB * 64 * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16;  // one activation image incl. its zero region
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* bufX = lds;
@@ -1014,11 +1016,12 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             TSTAMP(0);
             wave_stagger();
             auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB, E>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
-            conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB, E>(bufT, acc));
+            if constexpr (WGB == 2) conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB, E>(bufT, acc));
+            else conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab);
             TSTAMP(1);
             conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
 #pragma unroll
-            for (int j = 2 * WGB; j < 4 * WGB; j++)                            // second position half; the first went out under the last tap
+            for (int j = (WGB == 2 ? 2 * WGB : 0); j < 4 * WGB; j++)           // second position half; the first went out under the last tap (2-board form)
 #pragma unroll
                 for (int i = 0; i < 4; i++) epi_t(i, j);
             TSTAMP(2);
@@ -1026,11 +1029,12 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             TSTAMP(3);
             wave_stagger();
             auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB, E>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
-            conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB, E>(bufX, acc));   // reads bufT
+            if constexpr (WGB == 2) conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB, E>(bufX, acc));   // reads bufT
+            else conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab);
             TSTAMP(4);
             if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
 #pragma unroll
-            for (int j = 2 * WGB; j < 4 * WGB; j++)
+            for (int j = (WGB == 2 ? 2 * WGB : 0); j < 4 * WGB; j++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) epi_x(i, j);
             TSTAMP(5);
@@ -1201,6 +1205,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         prm.w[i] = (const uint4*)w_packed[i]; prm.b[i] = bias[i];
     }
     const size_t lds = 2 * ((size_t)(2 * 64) * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16) + 9 * 8 * 64 * sizeof(int);   // two images + tap address table
+    const size_t lds1 = 2 * ((size_t)64 * (NN_COUT * 2 + NN_PAD16) + NN_ZERO16) + 9 * 4 * 64 * sizeof(int);         // the one-board form
     static bool attr_flags[NN_MAX_DEVICES] = {};                       // function attributes are per device
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
@@ -1212,9 +1217,14 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         attr_set = true;
     }
-    const int n_tiles = (n_boards + 1) / 2, n_cu = device_cus();
+    const int n_cu = device_cus();
+    // one board per workgroup while every board can have a CU of its own (and no diagnostic build is asked for); flags SZ_NN_TOWER_WGB1 / _WGB2 force a form (tests)
+    const bool one = !g_tower_stamps && ((flags & SZ_NN_TOWER_WGB1) || (n_boards <= n_cu && !(flags & SZ_NN_TOWER_WGB2)));
+    const int n_tiles = one ? n_boards : (n_boards + 1) / 2;
     const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
     unsigned long long pace_add = 0, *pace_slot = nullptr;     // the arrival counters advance only when the launch went out (a failed launch leaves them consistent)
     {   // XCD-paced tile rounds (see the kernel); SZ_NN_PACE=0 switches them off.  The counters are per device and not thread-safe: one engine thread per GPU
@@ -1231,7 +1241,11 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         }
     }
 #define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
-    if ((flags & SZ_NN_F16) && g_tower_stamps)
+    if (one && (flags & SZ_NN_F16))
+        hipLaunchKernelGGL((k_tower16_bf16<0, ElemF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
+    else if (one)
+        hipLaunchKernelGGL((k_tower16_bf16<0, ElemBF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
+    else if ((flags & SZ_NN_F16) && g_tower_stamps)
         hipLaunchKernelGGL((k_tower16_bf16<1, ElemF16>), grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
     else if (flags & SZ_NN_F16)
         hipLaunchKernelGGL((k_tower16_bf16<0, ElemF16>), grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);

@@ -48,6 +48,7 @@ class FastPolicyNet:
         self.operands = operands
         self.f16 = operands == "fp16"
         self.eflag = N.SZ_NN_F16 if self.f16 else 0
+        self.force_wgb = 0                    # tests: N.SZ_NN_TOWER_WGB1 / _WGB2 force the one- / two-board workgroup form of the persistent tower
         if device is None:                   # the GPU the fp32 module lives on, else this process's current device (never a silent cuda:0)
             pdev = next(model.parameters()).device
             device = pdev if pdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
@@ -157,7 +158,7 @@ class FastPolicyNet:
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B, in_bits | self.eflag,
+            N.check(N.lib().sz_nn_tower_bf16(C.c_void_p(planes.data_ptr()), self._tower_w, self._tower_b, len(self.blocks), C.c_void_p(a.data_ptr()), B, in_bits | self.eflag | self.force_wgb,
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sz_nn_tower_bf16")
             if ev is not None:
                 ev[1].record()

@@ -250,6 +250,16 @@ def test_fp16_operand_network_matches_fp32_policynn():
         assert float((y - y_ref).norm() / y_ref.norm()) < 3e-3 and e16 < 3e-3 and e16 < eb / 3, (e16, eb)       # and at least 3x closer than bf16 operands
         assert float((v.view(-1) - v_ref.view(-1)).abs().max()) < 5e-3
         assert torch.allclose(pi.sum(1), torch.ones(B, device="cuda"), atol=1e-5) and float((pi.log() - pi_ref.log()).abs().max()) < 5e-3
+        # one board per workgroup (the default up to #CUs boards) and two give the same bits, for both operand types: a board's result does not depend on the batch
+        with torch.no_grad():
+            for fnet in (f16, b16):
+                fnet.force_wgb = N.SZ_NN_TOWER_WGB1
+                p1, v1 = (t.clone() for t in fnet(planes_nchw_to_nhwc128(x), inference=True))
+                fnet.force_wgb = N.SZ_NN_TOWER_WGB2
+                p2, v2 = (t.clone() for t in fnet(planes_nchw_to_nhwc128(x), inference=True))
+                fnet.force_wgb = 0
+                p0, v0 = (t.clone() for t in fnet(planes_nchw_to_nhwc128(x), inference=True))
+                assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(p0, p1) and torch.equal(v0, v1)
 
 
 def test_split_precision_network_matches_fp32_policynn():

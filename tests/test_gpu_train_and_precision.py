@@ -146,16 +146,16 @@ def test_split_precision_network_searches_like_fp32():
 
 
 # ------------------------------------------------------------------------------------------------ 3. ragged self-play: refill + compaction
-@pytest.mark.parametrize("kind,n_games,n_slots", [("fast", 12, 5), ("split", 12, 5), ("split", 300, 130)])
+@pytest.mark.parametrize("kind,n_games,n_slots", [("fast", 12, 5), ("split", 12, 5), ("split", 300, 130), ("fast", 300, 130), ("fp16", 300, 130)])
 def test_refill_and_compaction_give_identical_per_game_records(kind, n_games, n_slots):
     """sim.py:102-123 plays exactly num_games games.  The product runs them on fewer board slots than games (slot refill) and evaluates
     only the boards that still play (compaction); per-game records must be bit-identical to the plain run (one slot per game, no
-    compaction), because a game's results do not depend on what runs beside it.  Both MFMA networks: the bf16 tower (strictly per-board kernels)
-    and the split-precision network, whose 300-game case also crosses from two boards per workgroup (300 boards) to one (130 and fewer)."""
+    compaction), because a game's results do not depend on what runs beside it.  All MFMA networks (bf16 / f16 operands, split precision); the
+    300-game cases also cross from two boards per workgroup (300 boards) to one (130 and fewer)."""
     from sigma_zero_amd.fastnet import SplitPolicyNet
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
-    fast = FastPolicyNet(net) if kind == "fast" else SplitPolicyNet(net)
+    fast = FastPolicyNet(net) if kind == "fast" else FastPolicyNet(net, operands="fp16") if kind == "fp16" else SplitPolicyNet(net)
     args = {"C": 2, "num_searches": 10 if n_games == 12 else 4}
     sch = [(3 * g + 5) % 960 for g in range(n_games)]
     caps = [6, 9, 14, 40, 11, 40, 7, 40, 25, 40, 40, 13] if n_games == 12 else [3 + (g * 7) % 6 for g in range(n_games)]    # ragged: games are cut at different plies (stand-in for different game lengths)
