@@ -328,3 +328,27 @@ def test_config0_whole_game_with_split_precision_network(golden_dir):
     with open(os.path.join("gpurun_out", "config0_split_agreement.txt"), "w") as f:
         f.write("%d of %d plies identical\n" % (agree, n_ref))
     assert len(h["actions"]) == n_ref and agree == n_ref            # measured: 361 of 361 (deterministic: same kernel, same order on every MI355X)
+
+
+@pytest.mark.parametrize("operands", ["fp16", "bf16"])
+def test_config0_whole_game_with_the_fast_networks(golden_dir, operands):
+    """the same configs[0] game with the fast inference network (FastPolicyNet on f16 / bf16 operands): how many plies of the reference's fp32 CPU game it
+    reproduces before a visit falls the other way (a record, written to gpurun_out/; the game is one chain of 361 searches: the first differing visit
+    distribution changes everything after it, so this is a much harsher measure than the per-position agreement of test_gpu_train_and_precision.py)"""
+    from sigma_zero_amd.fastnet import FastPolicyNet
+    case = _load(golden_dir, "chess_config0_game.npz")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    net = FastPolicyNet(sz.policyNN({}).cuda().eval(), operands=operands)
+    h = sz.generate_training_data(net, 1, {"C": 2, "num_searches": 10}, None, True)
+    n_ref = len(case["rewards"])
+    agree = 0
+    for k in range(min(len(h["actions"]), n_ref)):
+        a, b = case["act_off"][k], case["act_off"][k + 1]
+        if not np.array_equal(pack_planes(h["states"][k].numpy()), case["states"][k]) or list(h["actions"][k].values()) != case["act_probs"][a:b].tolist():
+            break
+        agree += 1
+    print("configs[0] game with %s operands: %d of %d plies identical to the reference's CPU run" % (operands, agree, n_ref))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "config0_%s_agreement.txt" % operands), "w") as f:
+        f.write("%d of %d plies identical\n" % (agree, n_ref))
+    assert agree >= 1 and np.array_equal(pack_planes(h["states"][0].numpy()), case["states"][0])        # same start position (Chess960 index 864), same first search at least
