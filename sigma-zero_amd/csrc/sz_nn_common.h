@@ -163,14 +163,17 @@ __device__ __forceinline__ int tile_row(int j, int p16) {
 }
 
 // LDS byte offset (inside its image) that lane (p16, kg) reads for position tile j under tap `tap` — see conv_kloop16 for the zero region
-template <int PITCH, int NTAPS, int WGB>
+// SWZ (the split-precision images): the 16-byte chunk index of a row's data is XOR-ed with bit 2 of the row's position (chunk ^ ((row >> 2) & 1), i.e. the two
+// lane quarters kg, kg^1 trade places on rows 4..7 of every 8): it makes the epilogue's ds_write_b128 (8 lanes = 8 consecutive rows at one channel offset)
+// conflict-free and leaves ds_read_b128 conflict-free (slot 2*row + (kg ^ g) is still a permutation per lane group).
+template <int PITCH, int NTAPS, int WGB, bool SWZ = false>
 __device__ __forceinline__ int conv_tap_addr16(int tap, int j, int p16, int kg) {
     const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
     const int row0 = tile_row<WGB>(j, p16), pos = row0 & 63;   // position inside its board (board = row0 >> 6)
     const int y = (pos >> 3) + dy, x = (pos & 7) + dx;
     const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
     const int vrow = pos + 8 * dy + dx;
-    return ok ? ((row0 >> 6) * 64 + y * 8 + x) * PITCH + kg * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
+    return ok ? ((row0 >> 6) * 64 + y * 8 + x) * PITCH + (SWZ ? (kg ^ ((x >> 2) & 1)) : kg) * 16 : WGB * 64 * PITCH + ((2 * vrow + kg) & 15) * 16;
 }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[sigmazero] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return SZ_ERR_HIP; } } while (0)

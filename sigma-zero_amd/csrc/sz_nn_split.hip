@@ -23,6 +23,11 @@
 #include "sz_nn_common.h"
 
 #define NN_MAX_CONVS_SPLIT 129                             // the k-step offset of the weight stream is a 32-bit byte offset: 36 + 72*128 k-steps x 32 KiB
+#ifndef SP_PF
+#define SP_PF 1                                            // weight prefetch distance in k-steps (1,536 matrix-pipe cycles each with two boards).  -DSP_PF=2 (measured, profiles/r03q_pf.txt):
+                                                           // K loop unchanged (108.3k vs 108.4k cycles: the loop does not wait for weights), 30 registers more spilled around the epilogues
+#endif
+#define SP_RING (SP_PF == 1 ? 2 : 4)                       // named ring slots (compile-time indices ks & (SP_RING-1)); SP_PF + 1 of them are live at any time
 #define SP_KSTEP_U4 2048                                   // uint4 per k-step of the weight stream: 16 co tiles x 64 lanes hi, then the same for lo
 
 template <int WGB> struct SplitGeom {
@@ -37,20 +42,20 @@ template <int WGB> struct SplitGeom {
 
 // One convolution's K loop on hi/lo operands.  B images: hi at byte offset offH of `lds`, lo at offL (BLO = false: the input is exact in bf16 —
 // the 0/1 planes of the stem — and only w_hi*x + w_lo*x are formed).  Weight stream: global k-steps ks_base .. ks_base + 9*CIN/32 - 1; on entry
-// ring[ks_base & 1] holds k-step ks_base; on exit ring[ks_after & 1]... holds k-step `ks_after` (the next convolution's first, or the stem's of
-// the next tile), fetched under this convolution's last k-step.
+// the ring holds k-steps ks_base .. ks_base + SP_PF - 1; on exit it holds k-steps ks_after .. ks_after + SP_PF - 1 (the next convolution's first ones, or the
+// stem's of the next tile), fetched under this convolution's last k-steps.
 template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */,
           int NTAPS = 9 /* 1: a 1x1 convolution on the same images (conv_p1 of the fused heads) */>
 __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int offH, const int offL, const int* addr_tab, const WSrc& wr,
                                             const uint32_t ks_base, const uint32_t ks_after, const float* __restrict__ bias,
-                                            f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[2][8]) {
+                                            f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[SP_RING][8]) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;
     constexpr int KSTEPS = CIN / 32;
     constexpr int NJ = 4 * WGB, G = WGB;                   // position tiles; groups of 4 tiles per k-step
     constexpr int NPROD = BLO ? 3 : 2;
     constexpr bool SKIPROWS = WGB == 2 && NN_ROWSKIP && NTAPS == 9;
     static_assert(NTAPS == 9 || NTAPS == 1, "3x3 or 1x1");
-    static_assert(KSTEPS % 2 == 0, "ring slots must be compile-time indices");
+    static_assert(KSTEPS % SP_RING == 0, "ring slots must be compile-time indices");
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));                         // opaque per call: hipcc otherwise hoists the stem's 72 tap addresses out of the tile loop and spills them
     const int wave = threadIdx.x >> 6;
@@ -96,8 +101,9 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
         }
 #pragma unroll
         for (int kc = 0; kc < KSTEPS; kc++) {
-            const int slot = kc & 1;                       // ks_base and tap*KSTEPS are even
-            const uint32_t ks_next = (kc == KSTEPS - 1 && tap == NTAPS - 1) ? ks_after : ks_base + (uint32_t)(tap * KSTEPS + kc + 1);
+            const int slot = kc & (SP_RING - 1);           // ks_base and tap*KSTEPS are multiples of SP_RING
+            // the k-step SP_PF ahead: this convolution's, or (from its last SP_PF k-steps) the first ones of what follows it in the stream
+            const uint32_t ks_next = (kc + SP_PF >= KSTEPS && tap == NTAPS - 1) ? ks_after + (uint32_t)(kc + SP_PF - KSTEPS) : ks_base + (uint32_t)(tap * KSTEPS + kc + SP_PF);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int buf = (kc * G + g) & 1;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                             } else if (q < 16 && g == 0) {
                                 // weights of the next k-step (this convolution's, the next convolution's, or the next tile's stem)
                                 const int f = q - 8;
-                                if (!(ABL & 1)) ring[slot ^ 1][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+                                if (!(ABL & 1)) ring[(kc + SP_PF) & (SP_RING - 1)][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
                             }
                             asm volatile("" ::: "memory");
                             __builtin_amdgcn_sched_barrier(0);
@@ -177,28 +183,55 @@ template <int WGB, int MODE>
 __device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned char* lo_img, const f32x4 (&acc)[4][4 * WGB], float (&xres)[4][4 * WGB][4]) {
     constexpr int PITCH = NN_COUT * 2 + NN_PAD16;
     int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));                         // opaque per call: the 64 store addresses are not hoisted out of the tile loop (and spilled)
+    asm volatile("" : "+v"(lane));                         // opaque per call: the store addresses are not hoisted out of the tile loop (and spilled)
     const int wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4 * WGB; j++) {
         const int row = tile_row<WGB>(j, p16);
+        const int rowoff = row * PITCH, g = (row >> 2) & 1;          // g: the images' chunk swizzle (conv_tap_addr16 SWZ)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int co = (wave * 4 + i) * 16 + 4 * kg;
-            f32x4 v = acc[i][j];
+        for (int ip = 0; ip < 4; ip += 2) {
+            uint2 h[2], l[2];
+            // the AGPR moves are volatile asm (they keep their program order): all eight reads first, then the arithmetic, then all eight writes, so that
+            // no instruction waits for the one in front of it (value by value the chain read -> add -> max -> write ran at 6.8 cycles per instruction)
+            float r[2][4];
+            f32x4 v[2];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (MODE == 2) v[k] += from_agpr(xres[i][j][k]);
-                v[k] = relu_f32(v[k]);
-                if (MODE != 1) xres[i][j][k] = to_agpr(v[k]);
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[d][k] = MODE == 2 ? from_agpr(xres[ip + d][j][k]) : 0.f;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                v[d] = acc[ip + d][j];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (MODE == 2) v[d][k] += r[d][k];
+                    v[d][k] = relu_f32(v[d][k]);
+                }
             }
-            uint2 h, l;
-            h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]);
-            l.x = pack_bf16x2(v[0] - bf16_lo(h.x), v[1] - bf16_hi(h.x));
-            l.y = pack_bf16x2(v[2] - bf16_lo(h.y), v[3] - bf16_hi(h.y));
-            *(uint2*)(hi_img + row * PITCH + co * 2) = h;
-            *(uint2*)(lo_img + row * PITCH + co * 2) = l;
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (MODE != 1) xres[ip + d][j][k] = to_agpr(v[d][k]);
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                h[d].x = pack_bf16x2(v[d][0], v[d][1]); h[d].y = pack_bf16x2(v[d][2], v[d][3]);
+                l[d].x = pack_bf16x2(v[d][0] - bf16_lo(h[d].x), v[d][1] - bf16_hi(h[d].x));
+                l[d].y = pack_bf16x2(v[d][2] - bf16_lo(h[d].y), v[d][3] - bf16_hi(h[d].y));
+            }
+            // The lane holds 4 channels (8 B) of tile ip and 4 of tile ip + 1; its partner in the neighbouring lane quarter (lane ^ 16) holds the adjacent 4 of each.
+            // v_permlane16_swap trades them so that an even quarter ends up with 8 consecutive channels of tile ip and an odd one with 8 of tile ip + 1: one
+            // 16-byte store per lane and image instead of two 8-byte ones, and (with the chunk swizzle) no bank conflict: the 8-byte stores were 4-way
+            // conflicted and made the epilogue LDS-bound (4,096 LDS cycles per convolution and CU against 4.5-5.9k exposed; profiles/r03p: 2.45e8 conflict cycles).
+            const auto hx = __builtin_amdgcn_permlane16_swap(h[0].x, h[1].x, false, false), hy = __builtin_amdgcn_permlane16_swap(h[0].y, h[1].y, false, false);
+            const auto lx = __builtin_amdgcn_permlane16_swap(l[0].x, l[1].x, false, false), ly = __builtin_amdgcn_permlane16_swap(l[0].y, l[1].y, false, false);
+            const int it = ip + (kg & 1);                                        // the tile this lane now holds 8 channels of
+            const int chunk = ((wave * 4 + it) * 16 + 4 * (kg & 2)) >> 3;        // their 16-byte chunk inside the row
+            const int off = rowoff + ((chunk ^ g) << 4);
+            *(uint4*)(hi_img + off) = make_uint4(hx[0], hy[0], hx[1], hy[1]);
+            *(uint4*)(lo_img + off) = make_uint4(lx[0], ly[0], lx[1], ly[1]);
         }
     }
 }
@@ -222,7 +255,7 @@ struct SplitHeadsParams {
 // whether it ran alone in a workgroup, beside another board, at batch 1 or 4096 (the self-play records of a game do not depend on the batch it ran in).
 template <int WGB>
 __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* addr_tab, const WSrc& wr, const uint32_t ks_p1, const float* __restrict__ bias_p1,
-                                                 const SplitHeadsParams& hp, f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[2][8], float (&xres)[4][4 * WGB][4],
+                                                 const SplitHeadsParams& hp, f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[SP_RING][8], float (&xres)[4][4 * WGB][4],
                                                  const int board0, const int n_boards) {
     using GEO = SplitGeom<WGB>;
     constexpr int NJ = GEO::NJ, NT = WGB, PITCH = GEO::PITCH;          // NT: position tiles per wave in conv_p2
@@ -238,10 +271,11 @@ __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* 
         if (row < WGB * 64) {
             const unsigned char* ph = imgH + row * PITCH;
             const unsigned char* pl = imgL + row * PITCH;
+            const int g = (row >> 2) & 1;                  // the images' chunk swizzle
             float sv = 0.f;
 #pragma unroll 4
             for (int c8 = 0; c8 < 32; c8++) {
-                const uint4 h = *(const uint4*)(ph + c8 * 16), l = *(const uint4*)(pl + c8 * 16);
+                const uint4 h = *(const uint4*)(ph + ((c8 ^ g) << 4)), l = *(const uint4*)(pl + ((c8 ^ g) << 4));
                 const float4 w0 = ((const float4*)hp.wv)[c8 * 2], w1 = ((const float4*)hp.wv)[c8 * 2 + 1];
                 sv = __builtin_fmaf(w0.x, bf16_lo(h.x) + bf16_lo(l.x), sv); sv = __builtin_fmaf(w0.y, bf16_hi(h.x) + bf16_hi(l.x), sv);
                 sv = __builtin_fmaf(w0.z, bf16_lo(h.y) + bf16_lo(l.y), sv); sv = __builtin_fmaf(w0.w, bf16_hi(h.y) + bf16_hi(l.y), sv);
@@ -370,18 +404,20 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
     }
     int* addr_tab = (int*)(lds + GEO::TAB);
     for (int e = threadIdx.x; e < 9 * NJ * 64; e += 256)
-        addr_tab[e] = conv_tap_addr16<GEO::PITCH, 9, WGB>(e / (NJ * 64), (e >> 6) % NJ, e & 15, (e >> 4) & 3);
+        addr_tab[e] = conv_tap_addr16<GEO::PITCH, 9, WGB, true>(e / (NJ * 64), (e >> 6) % NJ, e & 15, (e >> 4) & 3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_tiles = (n_boards + WGB - 1) / WGB;
     const int n_convs = 1 + 2 * n_blocks;
     const WSrc wr = wfrag_rsrc(wstream);
     f32x4 acc[4][NJ];
     float xres[4][NJ][4];                                              // the residual x (exact f32), one value per AGPR
-    uint4 ring[2][8];
-    {   // k-step 0 of the stem
+    uint4 ring[SP_RING][8];
+    {   // the first SP_PF k-steps of the stem
         const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
 #pragma unroll
-        for (int f = 0; f < 8; f++) ring[0][f] = ld_wfrag(wr, (size_t)(f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+        for (int k = 0; k < SP_PF; k++)
+#pragma unroll
+            for (int f = 0; f < 8; f++) ring[k][f] = ld_wfrag(wr, (size_t)k * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
     }
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
