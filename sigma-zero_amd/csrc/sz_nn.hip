@@ -34,6 +34,14 @@
 // measured with tools/block_ab.py, all-streaming +3 % slower (the residual re-read then misses), stores or residual alone within noise).
 #include "sz_nn_common.h"
 
+// K loop of the persistent tower: ONE explicit s_waitcnt in the last MFMA gap of every half-step (it carries no memory instruction) for everything the next
+// half-step consumes — lgkmcnt(0) for its activation fragments, plus vmcnt(8) at the end of a k-step for the next k-step's weights (two k-steps of loads stay in
+// flight).  hipcc otherwise puts a counted wait in front of each first use, i.e. into the very gaps that also issue a load: 1,276 -> 523 s_waitcnt in the kernel,
+// BasicBlock 81,440 -> 80,196 cycles, launch 7.34 -> 7.24 ms (same box, interleaved: profiles/r03u_explicit_wait_ab.txt).  0 = off (A/B), 1 = LDS only.
+#ifndef NN_EXPLICIT_WAIT
+#define NN_EXPLICIT_WAIT 2
+#endif
+
 
 // ---- the K loop: acc[i][j] += W[tap,k] x Act[tap,k]^T over all taps and channels ----------------------------
 // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches to their uses:
@@ -332,6 +340,13 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                                 else if (hs == 0 && ks + PF < TOTAL_KS)
                                     aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(ks + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
                             }
+#if NN_EXPLICIT_WAIT
+                            // last gap of a half-step: one wait for everything the next half-step consumes (see NN_EXPLICIT_WAIT)
+                            if (PEEL && m == NI * NH - 1) {
+                                if (NN_EXPLICIT_WAIT >= 2 && hs == 1) __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8) lgkmcnt(0): the next k-step's weights (two k-steps of loads stay in flight)
+                                else __builtin_amdgcn_s_waitcnt(0xC07F);                                     // lgkmcnt(0)
+                            }
+#endif
                             asm volatile("" ::: "memory");
                             __builtin_amdgcn_sched_barrier(0);
                         }

@@ -27,6 +27,9 @@
 #define SP_PF 1                                            // weight prefetch distance in k-steps (1,536 matrix-pipe cycles each with two boards).  -DSP_PF=2 (measured, profiles/r03q_pf.txt):
                                                            // K loop unchanged (108.3k vs 108.4k cycles: the loop does not wait for weights), 30 registers more spilled around the epilogues
 #endif
+#ifndef SP_EXPLICIT_WAIT
+#define SP_EXPLICIT_WAIT 1
+#endif
 #define SP_RING (SP_PF == 1 ? 2 : 4)                       // named ring slots (compile-time indices ks & (SP_RING-1)); SP_PF + 1 of them are live at any time
 #define SP_KSTEP_U4 2048                                   // uint4 per k-step of the weight stream: 16 co tiles x 64 lanes hi, then the same for lo
 
@@ -140,6 +143,16 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                                 const int f = q - 8;
                                 if (!(ABL & 1)) ring[(kc + SP_PF) & (SP_RING - 1)][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
                             }
+#if SP_EXPLICIT_WAIT
+                            // one explicit wait in a gap that carries no memory instruction, instead of hipcc's counted wait in front of every first use
+                            // (sz_nn.hip NN_EXPLICIT_WAIT): before the third product for the lo fragments, at the end of a group for the next group's hi
+                            // fragments, at the end of a k-step also for the next k-step's weights (SP_PF - 1 k-steps of 8 loads stay in flight)
+                            if (q == 31 && NPROD == 3) __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0)
+                            if (q == NPROD * 16 - 1) {
+                                if (g == G - 1) __builtin_amdgcn_s_waitcnt(0x0070 | ((SP_PF - 1) * 8));                            // vmcnt(8 * (SP_PF - 1)) lgkmcnt(0)
+                                else __builtin_amdgcn_s_waitcnt(0xC07F);                                                         // lgkmcnt(0)
+                            }
+#endif
                             asm volatile("" ::: "memory");
                             __builtin_amdgcn_sched_barrier(0);
                         }
