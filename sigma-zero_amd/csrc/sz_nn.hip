@@ -41,6 +41,9 @@
 #ifndef NN_EXPLICIT_WAIT
 #define NN_EXPLICIT_WAIT 2
 #endif
+#ifndef NN_TAPGAP
+#define NN_TAPGAP 1                                        // tap bookkeeping (table reads, row addresses) inside MFMA gaps; 0 = between the taps (A/B)
+#endif
 
 
 // ---- the K loop: acc[i][j] += W[tap,k] x Act[tap,k]^T over all taps and channels ----------------------------
@@ -291,7 +294,12 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     auto tap_body = [&](const int tap, auto first_tag, auto skip_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int SK = decltype(skip_tag)::value;          // SKIPROWS: 1 = position tile 0 idle under this tap (dy = -1), 2 = the last position tile idle (dy = +1)
-        if (tap + 1 < NTAPS) {
+        // Tap bookkeeping inside MFMA gaps (persistent tower with the address table): the next tap's NJ table entries are read in the load-free gaps of the
+        // first k-step's second half-step, the NJ row addresses are formed in those of the last k-step's — one instruction per gap — instead of a
+        // block of ~15 instructions between two taps with the matrix pipe idle (NN_TAPGAP=0: A/B).
+        constexpr bool TAPGAP = NN_TAPGAP && PEEL && NN_ILV && NH + NJ <= NI * (NH - 1);
+        const bool in_gaps = TAPGAP && addr_tab != nullptr;
+        if (tap + 1 < NTAPS && !in_gaps) {
 #pragma unroll
             for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
         }
@@ -324,25 +332,32 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                     bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
 #pragma unroll
                     for (int j = 0; j < NH; j++) {
-                        if (!((SK == 1 && hs == 0 && j == 0) || (SK == 2 && hs == 1 && j == NH - 1)))
-                            acc[i][hs * NH + j] = E::mfma(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j]);
-                        if (NN_ILV) {
+                        const bool idle_hs = (SK == 1 && hs == 0) || (SK == 2 && hs == 1);            // this half-step has an idle position tile (border row)
+                        const bool idle = idle_hs && j == (SK == 1 ? 0 : NH - 1);
+                        if (!idle) acc[i][hs * NH + j] = E::mfma(a, bfrag[hs][j], (FIRST && kc == 0) ? binit[i] : acc[i][hs * NH + j]);
+                        if (NN_ILV && !idle) {
                             // one memory instruction per MFMA gap (an MFMA leaves 8 of its 16 cycles for other issue): first the next
-                            // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2)
-                            const int m = i * NH + j;
+                            // half-step's activations (LDS), then - in the first half-step - the weights PF k-steps ahead (L2).  m counts the MFMAs
+                            // actually issued (a skipped border tile has no gap: its memory instruction would land in its neighbour's)
+                            const int NR = idle_hs ? NH - 1 : NH, m = i * NR + (idle_hs && SK == 1 ? j - 1 : j);
                             if (m < NH) {
                                 if ((ABL & 2) || (SK == 2 && hs == 0 && m == NH - 1)) {}
                                 else if (hs == 0) bfrag[1][m] = LD(bcur[NH + m] + kc * 64);
                                 else if (kc + 1 < KSTEPS) { if (!(SK == 1 && m == 0)) bfrag[0][m] = LD(bcur[m] + (kc + 1) * 64); }
                                 else if (tap + 1 < NTAPS) { if (!(SK == 1 && m == 0 && tap + 1 < 3)) bfrag[0][m] = LD(abs_addr(bnxt[m])); }   // tile 0 is needed again from tap 3 on
-                            } else if (m < NH + NI) {
+                            } else if (m < NH + NI && hs == 0) {
                                 if (ABL & 1) {}
-                                else if (hs == 0 && ks + PF < TOTAL_KS)
+                                else if (ks + PF < TOTAL_KS)
                                     aring[(kc + PF) & (RING - 1)][m - NH] = ld_wfrag(wr, (size_t)(ks + PF) * W_KSTEP_STRIDE, wlane + (m - NH) * 1024);
+                            } else if (TAPGAP && hs == 1 && m >= NH && m < NH + NJ) {
+                                if (in_gaps) {
+                                    if (kc == 0) bnxt[m - NH] = tap_addr(tap + 1 < NTAPS ? tap + 1 : tap, m - NH);
+                                    else if (kc == KSTEPS - 1) bcur[m - NH] = abs_addr(bnxt[m - NH]);
+                                }
                             }
 #if NN_EXPLICIT_WAIT
                             // last gap of a half-step: one wait for everything the next half-step consumes (see NN_EXPLICIT_WAIT)
-                            if (PEEL && m == NI * NH - 1) {
+                            if (PEEL && m == NI * NR - 1) {
                                 if (NN_EXPLICIT_WAIT >= 2 && hs == 1) __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8) lgkmcnt(0): the next k-step's weights (two k-steps of loads stay in flight)
                                 else __builtin_amdgcn_s_waitcnt(0xC07F);                                     // lgkmcnt(0)
                             }
@@ -355,8 +370,10 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (!in_gaps) {
 #pragma unroll
-        for (int j = 0; j < NJ; j++) bcur[j] = abs_addr(bnxt[j]);
+            for (int j = 0; j < NJ; j++) bcur[j] = abs_addr(bnxt[j]);
+        }
     };
     constexpr bool SPLIT = !std::is_same<EPI, std::nullptr_t>::value && NTAPS == 9 && NN_ILV && PEEL && KSTEPS % RING == 0;
     // Last tap with its position halves in sequence (SPLIT): phase A finishes the accumulators of the first half (board 0), phase B runs the second
@@ -386,6 +403,9 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                         } else if (kc == KSTEPS - 1 && (m == 2 * NH || m == 3 * NH)) {
                             epi0(m == 2 * NH ? 0 : 1, -1);                                                     // stage -1: operand prefetch for the first two tiles
                         }
+#if NN_EXPLICIT_WAIT >= 2
+                        if (m == NI * NH - 1) __builtin_amdgcn_s_waitcnt(0x0078);                              // vmcnt(8) lgkmcnt(0), as in tap_body
+#endif
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     }

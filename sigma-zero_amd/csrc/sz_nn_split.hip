@@ -117,10 +117,12 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                         const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][prod == 1 ? 4 + i : i]);
 #pragma unroll
                         for (int m = 0; m < 4; m++) {
-                            const bool idle = SKIPROWS && ((SK == 1 && g == 0 && m == 0) || (SK == 2 && g == G - 1 && m == 3));
-                            if (!idle) acc[i][g * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m], 0, 0, 0);
-                            // one memory instruction per MFMA gap
-                            const int q = prod * 16 + i * 4 + m;
+                            const bool idle_g = SKIPROWS && ((SK == 1 && g == 0) || (SK == 2 && g == G - 1));     // this group has an idle position tile (border row)
+                            const bool idle = idle_g && m == (SK == 1 ? 0 : 3);
+                            if (idle) continue;
+                            acc[i][g * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m], 0, 0, 0);
+                            // one memory instruction per MFMA gap; q counts the MFMAs actually issued in this group (a skipped tile has no gap of its own)
+                            const int NR = idle_g ? 3 : 4, q = (prod * 4 + i) * NR + (idle_g && SK == 1 ? m - 1 : m);
                             if (q < 4) {
                                 // lo fragments of THIS group (used by its third product, 32 gaps on)
                                 if constexpr (BLO && !(ABL & 2)) {
@@ -147,8 +149,8 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                             // one explicit wait in a gap that carries no memory instruction, instead of hipcc's counted wait in front of every first use
                             // (sz_nn.hip NN_EXPLICIT_WAIT): before the third product for the lo fragments, at the end of a group for the next group's hi
                             // fragments, at the end of a k-step also for the next k-step's weights (SP_PF - 1 k-steps of 8 loads stay in flight)
-                            if (q == 31 && NPROD == 3) __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0)
-                            if (q == NPROD * 16 - 1) {
+                            if (q == 8 * NR - 1 && NPROD == 3) __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0)
+                            if (q == NPROD * 4 * NR - 1) {
                                 if (g == G - 1) __builtin_amdgcn_s_waitcnt(0x0070 | ((SP_PF - 1) * 8));                            // vmcnt(8 * (SP_PF - 1)) lgkmcnt(0)
                                 else __builtin_amdgcn_s_waitcnt(0xC07F);                                                         // lgkmcnt(0)
                             }
