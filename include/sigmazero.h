@@ -236,7 +236,7 @@ int sz_nn_pack_split_head(const float* w_in /* conv_p2.weight [73,256] */, uint1
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */
 int sz_nn_debug_split_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
-/* diagnostic only: when set to a device buffer of 256*4*8 uint64, sz_nn_tower_bf16 launches its stamped build, which records
+/* diagnostic only: when set to a device buffer of 256*4*16 uint64, sz_nn_tower_bf16 launches its stamped build, which records
  * s_memtime at the phase boundaries of one block (tools/tower_stamps.py); NULL switches back to the shipped kernel */
 int sz_nn_debug_tower_stamps(void* dev_buffer, int32_t mode /* 1 = stamps; 2/3/4 = stamps + no weight loads / no LDS reads / neither (timing only) */);
 /* counter calibration only (tools/fetch_calib.py): reads `bytes` of src exactly once, 16 B per lane, with flat global loads (mode 0) or buffer loads (mode 1) */

@@ -274,6 +274,18 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         // head of the tap); abs_addr() adds the offset where the address is first used, at the end of the tap
         return addr_tab ? addr_tab[(tap * NJ + j) * 64 + lane] : conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
     };
+    // The stem (C_in = 128: row pitch 288 B) has no table of its own (LDS is full); given the 256-channel images' table it converts an entry instead of
+    // redoing the coordinate arithmetic (~50 VALU per tile and tap: the stem's K loop took 33k cycles for 17k of MFMAs, tools/tower_stamps.py tile stamps):
+    //   valid entry  row*544 + 16*kg  ->  row*288 + 16*kg = entry - 256*floor(entry / 544);   zero-region entry: same slot behind the 288-B rows
+    constexpr int TABPITCH = NN_COUT * 2 + NN_PAD16;
+    constexpr bool CONVERT = PITCH != TABPITCH;                 // only together with addr_tab
+    auto tab_convert = [&](int rel) -> int {
+        if constexpr (!CONVERT) return rel;
+        else {
+            const int row = (int)__umulhi((unsigned)rel, 7895161u);        // floor(rel / 544), exact for rel < 2^20 (7895161 = ceil(2^32 / 544))
+            return rel >= WGB * 64 * TABPITCH ? rel - WGB * 64 * (TABPITCH - PITCH) : rel - row * (TABPITCH - PITCH);
+        }
+    };
     // The LDS base of the dynamic shared array is a link-time constant (0 here) that hipcc cannot fold early: reading through `lds + offset` cost one
     // v_add_u32 v, 0, v in front of EVERY ds_read_b128 (64 per tap).  The base therefore goes into the row address once per tap, together with the
     // image offset, and the fragments are read through LDS-address-space pointers built from that integer: address + immediate offset, no VALU.
@@ -287,7 +299,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     int bcur[NJ], bnxt[NJ];
     bf16x8 bfrag[2][NH];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { bnxt[j] = tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
+    for (int j = 0; j < NJ; j++) { bnxt[j] = addr_tab ? tab_convert(tap_addr(0, j)) : tap_addr(0, j); bcur[j] = abs_addr(bnxt[j]); }
 #pragma unroll
     for (int j = 0; j < NH; j++)
         if (!(SKIPROWS && j == 0)) bfrag[0][j] = LD(bcur[j]);
@@ -301,7 +313,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
         const bool in_gaps = TAPGAP && addr_tab != nullptr;
         if (tap + 1 < NTAPS && !in_gaps) {
 #pragma unroll
-            for (int j = 0; j < NJ; j++) bnxt[j] = tap_addr(tap + 1, j);
+            for (int j = 0; j < NJ; j++) bnxt[j] = addr_tab ? tab_convert(tap_addr(tap + 1, j)) : tap_addr(tap + 1, j);
         }
 #pragma unroll
         for (int kc = 0; kc < KSTEPS; kc++) {
@@ -352,6 +364,7 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
                             } else if (TAPGAP && hs == 1 && m >= NH && m < NH + NJ) {
                                 if (in_gaps) {
                                     if (kc == 0) bnxt[m - NH] = tap_addr(tap + 1 < NTAPS ? tap + 1 : tap, m - NH);
+                                    else if (CONVERT && kc == 1) bnxt[m - NH] = tab_convert(bnxt[m - NH]);
                                     else if (kc == KSTEPS - 1) bcur[m - NH] = abs_addr(bnxt[m - NH]);
                                 }
                             }
@@ -999,6 +1012,8 @@ struct TowerParams {
 
 // STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
 // a buffer of their own; the shipped instantiation (STAMP = false) executes no stamp.
+// tile-level stamps (second tile of a workgroup) go behind the block stamps: slot 8192 + wave*8 + k
+#define TILESTAMP(k) do { if (STAMP_ && tile == (int)(blockIdx.x + gridDim.x)) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[8192 + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
 #define TSTAMP(k) do { if (STAMP_ && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
 // WGB = 1: ONE board per workgroup, for batches of at most #CUs boards (a search of one position, the tail of a self-play run): half the latency per forward
 // of a 2-board tile with an empty half.  Same accumulation order per output element, so a board's result does not depend on the form.
@@ -1026,6 +1041,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
     uint4 ring[4][4];                                                  // next convolution's first weight fragments, fetched under the current epilogue
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
+        TILESTAMP(0);
         conv_prefetch16<4>(prm.w[0], ring);
         if (prm.pace && threadIdx.x == 0) {
             // XCD-paced tile rounds: the 32 workgroups that share an XCD (blockIdx mod 8, round-robin dispatch) start every tile round together, so
@@ -1039,13 +1055,17 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             for (int spins = 0; spins < 512 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) __builtin_amdgcn_s_sleep(2);
         }
         __syncthreads();                                               // previous tile's output image fully read
+        TILESTAMP(1);
         if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16, E>(bufT, planes, board0, n_boards);
         else stage_tile<128, WGB, NN_PAD16>(bufT, planes, board0, n_boards, false);
         __syncthreads();
-        conv_kloop16<128, 9, WGB, 4, true, 0, false, E>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0]);  // stem (reads bufT): x = relu(bn(conv1(planes)))
+        TILESTAMP(2);
+        conv_kloop16<128, 9, WGB, 4, true, 0, false, E>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0], addr_tab);  // stem (reads bufT): x = relu(bn(conv1(planes)))
+        TILESTAMP(3);
         if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
         acc_to_lds16<WGB, E>(bufX, acc, nullptr, true);
         __syncthreads();
+        TILESTAMP(4);
         for (int blk = 0; blk < n_blocks; blk++) {
             const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
             TSTAMP(0);
@@ -1077,7 +1097,9 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             TSTAMP(6);
             if (STAMP_ && stamp_now && (threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
+        TILESTAMP(5);
         lds_to_out<WGB, NN_PAD16>(bufX, nullptr, out, board0, n_boards, false);
+        TILESTAMP(6);
     }
 }
 

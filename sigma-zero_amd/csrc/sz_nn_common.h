@@ -73,7 +73,7 @@ struct ElemF16 {
 };
 
 // ---- stage WGB boards' activations (NHWC rows of C_in bf16) into LDS, plus one zero row ---------------------
-template <int CIN, int WGB, int PAD = 16, bool NT = false>
+template <int CIN, int WGB, int PAD = 16, bool NT = false, bool SWZ = false /* chunk swizzle of the split-precision images: chunk ^ ((position >> 2) & 1) */>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards, bool skip) {
     constexpr int PITCH = CIN * 2 + PAD;
     constexpr int CHUNKS_PER_POS = CIN / 8;                // 16-B chunks per position
@@ -93,7 +93,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
 #pragma unroll
     for (int i = 0; i < PER_THREAD; i++) {
         const int c = tid + i * 256;
-        *(uint4*)(lds + (c / CHUNKS_PER_POS) * PITCH + (c % CHUNKS_PER_POS) * 16) = stage[i];
+        *(uint4*)(lds + (c / CHUNKS_PER_POS) * PITCH + ((c % CHUNKS_PER_POS) ^ (SWZ ? ((c / CHUNKS_PER_POS) >> 2) & 1 : 0)) * 16) = stage[i];
     }
     for (int c = tid; c < (PAD == NN_PAD16 ? NN_ZERO16 : PITCH) / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
 }
@@ -101,7 +101,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const uint16_t* _
 // ---- stage WGB boards from the engine's bit-packed planes (SZ_PLANES_NHWC128_BITS: 1 KiB per board) ----------
 // uint4 l of a board (l = psub*16 + cq): byte q = channels cq*8..cq*8+7 of position q*4 + psub.  Two threads share a
 // uint4 (q 0..7 / 8..15); each expands 8 bytes to 8 chunks of 8 elements (1.0 = E::ONE) and writes them to its LDS rows.
-template <int WGB, int PAD, class E = ElemBF16>
+template <int WGB, int PAD, class E = ElemBF16, bool SWZ = false>
 __device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16_t* __restrict__ in, int board0, int n_boards) {
     constexpr int PITCH = 128 * 2 + PAD;
     const uint4* src = (const uint4*)in + (size_t)board0 * 64;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void stage_tile_bits(unsigned char* lds, const uint16
             o.z = ((byte & 16) ? E::ONE : 0u) | ((byte & 32) ? (E::ONE << 16) : 0u);
             o.w = ((byte & 64) ? E::ONE : 0u) | ((byte & 128) ? (E::ONE << 16) : 0u);
             const int pos = (half * 8 + qq) * 4 + psub;
-            *(uint4*)(lds + (board * 64 + pos) * PITCH + cq * 16) = o;
+            *(uint4*)(lds + (board * 64 + pos) * PITCH + (cq ^ (SWZ ? (pos >> 2) & 1 : 0)) * 16) = o;
         }
     }
     for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) *(uint4*)(lds + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);

@@ -73,9 +73,19 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
 #pragma unroll
             for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
     }
+    // The stem's input image (C_in = 128, row pitch 288 B) is staged with the same chunk swizzle as the 256-channel images, so an entry of their tap table
+    // converts to it without coordinate arithmetic: valid entry row*544 + 16*chunk -> entry - 256*floor(entry / 544); zero-region entry: the same slot behind
+    // the 288-B rows (the arithmetic form cost ~50 VALU per tile and tap: the stem K loop ran at half speed)
+    constexpr int TABPITCH = NN_COUT * 2 + NN_PAD16;
     auto tap_addr = [&](int tap, int j) -> int {
-        if constexpr (TAB) return addr_tab[((NTAPS == 1 ? 4 : tap) * NJ + j) * 64 + lane];      // 1x1: the centre tap of the 3x3 table
-        else return conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
+        if constexpr (TAB) {
+            const int rel = addr_tab[((NTAPS == 1 ? 4 : tap) * NJ + j) * 64 + lane];             // 1x1: the centre tap of the 3x3 table
+            if constexpr (PITCH == TABPITCH) return rel;
+            else {
+                const int row = (int)__umulhi((unsigned)rel, 7895161u);                            // floor(rel / 544), exact for rel < 2^20
+                return rel >= WGB * 64 * TABPITCH ? rel - WGB * 64 * (TABPITCH - PITCH) : rel - row * (TABPITCH - PITCH);
+            }
+        } else return conv_tap_addr16<PITCH, NTAPS, WGB>(tap, j, p16, kg);
     };
     const int lds_base = (int)(uint32_t)(uintptr_t)lds;
     auto abs_addr = [&](int rel) -> int {
@@ -437,13 +447,13 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
         // nobody reads the images here: the previous tile ended with epilogue + barrier, its output went out from registers
-        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16>(imgL, planes, board0, n_boards);
-        else stage_tile<128, WGB, NN_PAD16>(imgL, planes, board0, n_boards, false);
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16, ElemBF16, true>(imgL, planes, board0, n_boards);
+        else stage_tile<128, WGB, NN_PAD16, false, true>(imgL, planes, board0, n_boards, false);
         __syncthreads();
         uint32_t ks = 0;
         const uint32_t ks_p1 = 36u + 72u * (uint32_t)(n_convs - 1);    // conv_p1's 8 k-steps follow the tower's in the stream
         const uint32_t ks_end = HEADS ? ks_p1 : 0u;                    // what the tower's last convolution prefetches: conv_p1, or the next tile's stem
-        split_kloop<128, WGB, false, false>(lds, GEO::IMG, GEO::IMG, nullptr, wr, ks, n_convs > 1 ? 36u : ks_end, bias, acc, ring);
+        split_kloop<128, WGB, false, true>(lds, GEO::IMG, GEO::IMG, addr_tab, wr, ks, n_convs > 1 ? 36u : ks_end, bias, acc, ring);
         ks += 36;
         __syncthreads();                                               // every wave is done reading the planes
         split_epilogue<WGB, 0>(imgH, imgL, acc, xres);

@@ -18,7 +18,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "split":          # the split-precision 
 if len(sys.argv) > 4:                                     # diagnostic build of the bf16 tower under the counters: 3 = no LDS fragment reads in the K loop, ...
     import ctypes as C
     from sigma_zero_amd import _native as N
-    stamps = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(256 * 4 * 16, dtype=torch.int64, device="cuda")
     N.check(N.lib().sz_nn_debug_tower_stamps(C.c_void_p(stamps.data_ptr()), int(sys.argv[4])), "stamps")
 for _ in range(12):
     fast.tower(planes)

@@ -20,13 +20,21 @@ modes = [int(m) for m in sys.argv[2:]] or [1]
 names = ["conv1 K loop", "epilogue1 (acc->LDS)", "barrier1", "conv2 K loop", "epilogue2 (residual)", "barrier2"]
 print("ideal K loop = 72 k-steps x 512 = 36864 MFMA cycles")
 for mode in modes:
-    buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(256 * 4 * 16, dtype=torch.int64, device="cuda")
     N.check(N.lib().sz_nn_debug_tower_stamps(C.c_void_p(buf.data_ptr()), mode), "stamps")
     for _ in range(3):
         fast.tower(planes)
     torch.cuda.synchronize()
     N.lib().sz_nn_debug_tower_stamps(None, 1)
-    s = buf.cpu().numpy().reshape(256, 4, 8).astype(np.float64)
+    raw = buf.cpu().numpy().astype(np.float64)
+    tl = raw[8192:].reshape(256 * 4, 8)
+    tl = tl[tl[:, 0] > 0]
+    if len(tl):
+        td = np.diff(tl[:, :7], axis=1)
+        for i, n in enumerate(["tile: pacing wait + barrier", "tile: stage planes + barrier", "tile: stem K loop", "tile: stem epilogue + barrier", "tile: %d blocks" % len(fast.blocks), "tile: output store"]):
+            print("  %-30s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (n, np.median(td[:, i]), np.percentile(td[:, i], 10), np.percentile(td[:, i], 90)))
+        print("  tile total median %.0f cycles" % np.median(tl[:, 6] - tl[:, 0]))
+    s = raw[:8192].reshape(256, 4, 8)
     s = s[s[:, :, 0] > 0].reshape(-1, 8)
     d = np.diff(s[:, :7], axis=1)
     print("mode %d (%s): waves with stamps: %d" % (mode, {1: "full", 2: "no weight loads", 3: "no LDS reads", 4: "MFMA only", 5: "border-row skipping OFF (all 72 tap-tiles multiply)"}[mode], len(s)))
