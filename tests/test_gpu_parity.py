@@ -496,15 +496,15 @@ def test_slot_refill_keeps_other_boards_intact():
     eng.close()
 
 
-@pytest.mark.parametrize("chess960", [True, False])
-def test_full_size_invariants_4096_boards_800_searches(chess960):
+@pytest.mark.parametrize("chess960,operands", [(True, "bf16"), (False, "bf16"), (True, "fp16")])
+def test_full_size_invariants_4096_boards_800_searches(chess960, operands):
     """BASELINE configs[2] (classical starts) and configs[4] (Chess960 starts) at full size through size-independent properties (the oracle cannot follow 3.3 M simulations): every
     simulation is accounted for, every root's child visits sum to S-1 (mcts.py:46,118), the sampled move is a visited root child,
     records are complete, no board reports an error, edge capacity is not approached."""
     from sigma_zero_amd.fastnet import FastPolicyNet
     B, S = 4096, 800
     torch.manual_seed(0)
-    fast = FastPolicyNet(sz.policyNN({}).cuda().eval())
+    fast = FastPolicyNet(sz.policyNN({}).cuda().eval(), operands=operands)      # bf16: the bench's headline network; fp16: the product's default self-play network
     eng = SelfPlayEngine(fast, {"C": 2, "num_searches": S}, B, chess960=chess960, learning=True, planes_dtype="bits128")
     prng = np.random.RandomState(5)
     eng.new_games(prng.randint(0, 960, size=B).tolist() if chess960 else [-1] * B)
