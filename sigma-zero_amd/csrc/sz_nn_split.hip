@@ -491,6 +491,89 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
     }
 }
 
+// =================================================================================================================
+// One 3x3 convolution (256 -> 256 channels, padding 1, no bias) on f32 NCHW tensors at the reference's precision class — for the TRAINING step
+// (train_RL.py:103-122 runs network.py's fp32 convolutions forward and backward through MIOpen: at batch 128 its fp32 Winograd takes 89 us per convolution,
+// 51 % of an optimiser step).  Same machinery as the inference tower: a workgroup takes one board, stages it as hi / lo bf16 images in LDS, runs split_kloop
+// (three MFMAs per product, f32 accumulate) over a 72-k-step weight stream and writes its 64 channels x 64 positions per wave back as f32.
+// Forward: y = conv(x, w).  Backward-data is the same kernel on the gradient with the weights transposed and flipped (sz_nn_pack_conv_split_dev, transposed = 1).
+// x, y: [n_boards][256][8][8] f32;  w_stream: 72 k-steps x {hi 16 KB, lo 16 KB} from sz_nn_pack_conv_split_dev.
+__global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __restrict__ x, const uint4* __restrict__ wstream, const float* __restrict__ zero_bias,
+                                                               float* __restrict__ y, int n_boards) {
+    constexpr int WGB = 1;
+    using GEO = SplitGeom<WGB>;
+    constexpr int NJ = GEO::NJ, PITCH = GEO::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* imgH = lds;
+    unsigned char* imgL = lds + GEO::IMG;
+    for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) {
+        *(uint4*)(imgH + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(imgL + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+    int* addr_tab = (int*)(lds + GEO::TAB);
+    for (int e = threadIdx.x; e < 9 * NJ * 64; e += 256)
+        addr_tab[e] = conv_tap_addr16<PITCH, 9, WGB, true>(e / (NJ * 64), (e >> 6) % NJ, e & 15, (e >> 4) & 3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WSrc wr = wfrag_rsrc(wstream);
+    f32x4 acc[4][NJ];
+    uint4 ring[SP_RING][8];
+    {
+        const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+#pragma unroll
+        for (int k = 0; k < SP_PF; k++)
+#pragma unroll
+            for (int f = 0; f < 8; f++) ring[k][f] = ld_wfrag(wr, (size_t)k * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+    }
+    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+        __syncthreads();                                               // the previous board's images are fully read
+        // stage: the board is 256 channels x 64 positions of f32, channel-major; a wave instruction reads 1 KiB = 4 channels x 64 positions, lane l holds positions
+        // 4*(l & 15) .. +3 of channel 4*q + (l >> 4); every value goes to its (position row, channel) slot of the hi and of the lo image (swizzled chunks)
+        const float4* src = (const float4*)(x + (size_t)board * 256 * 64);
+#pragma unroll 4
+        for (int q = wave; q < 64; q += 4) {
+            const float4 v = src[q * 64 + lane];
+            const int c = q * 4 + (lane >> 4), p0 = (lane & 15) * 4;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int row = p0 + k;
+                const int off = row * PITCH + (((c >> 3) ^ ((row >> 2) & 1)) << 4) + (c & 7) * 2;
+                const uint32_t hb = pack_bf16x2(vv[k], 0.f) & 0xFFFFu;
+                const uint32_t lb = pack_bf16x2(vv[k] - bf16_lo(hb), 0.f) & 0xFFFFu;
+                *(uint16_t*)(imgH + off) = (uint16_t)hb;
+                *(uint16_t*)(imgL + off) = (uint16_t)lb;
+            }
+        }
+        __syncthreads();
+        split_kloop<256, WGB, true, true>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring);      // the stream restarts for the next board
+        // acc tile (i, j): lane (p16, kg) holds channels (wave*4 + i)*16 + 4*kg + r, r = 0..3, of position j*16 + p16
+        float* dst = y + (size_t)board * 256 * 64;
+        const int p16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[(size_t)((wave * 4 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = acc[i][j][r];
+    }
+}
+
+// torch conv weight [256 co][256 ci][3][3] f32 (device) -> the 72-k-step hi / lo fragment stream of k_conv3x3_split_f32 (device), one thread per bf16 pair of
+// elements.  transposed = 1: the stream of the backward-data convolution, W'[ci][co][tap] = w[co][ci][8 - tap].
+__global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                   // over 72 k-steps x 16 tiles x 64 lanes x 8 elements
+    if (idx >= 72 * 16 * 64 * 8) return;
+    const int e = idx & 7, l = (idx >> 3) & 63, tile = (idx >> 9) & 15, ks = idx >> 13;
+    const int tap = ks >> 3, k32 = ks & 7;
+    const int co = tile * 16 + (l & 15), ci = k32 * 32 + 8 * (l >> 4) + e;
+    const float v = transposed ? w[((size_t)ci * 256 + co) * 9 + (8 - tap)] : w[((size_t)co * 256 + ci) * 9 + tap];
+    const uint32_t h = pack_bf16x2(v, 0.f) & 0xFFFFu;
+    const uint32_t lo = pack_bf16x2(v - bf16_lo(h), 0.f) & 0xFFFFu;
+    uint16_t* rec = stream + (size_t)ks * SP_KSTEP_U4 * 8;
+    rec[((size_t)tile * 64 + l) * 8 + e] = (uint16_t)h;
+    rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = (uint16_t)lo;
+}
+
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_mode = 1;
 
@@ -617,6 +700,31 @@ int sz_nn_forward_split(const void* planes, const void* w_stream, const float* b
     const int rc = launch_split(planes, w_stream, bias, n_blocks, tower_out, n_boards, flags, stream, &hp);
     if (rc != SZ_OK) return rc;
     return sz_nn_value_mlp(v1_scratch, fc1_w_t, fc1_b, fc2_w, fc2_b, value, n_boards, stream);
+}
+
+// Training-step convolutions at the reference's precision class (k_conv3x3_split_f32).  x, y: device [n_boards,256,8,8] f32 (NCHW, contiguous); w_stream: device buffer
+// of 72*2048*16 bytes written by sz_nn_pack_conv_split_dev; zero256: device [256] f32 zeros (the convolutions of network.py:28,30 have no bias).
+int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, void* stream) {
+    if (!x || !w_stream || !zero256 || !y || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    static bool attr_flags[NN_MAX_DEVICES] = {};
+    bool& attr_set = attr_flags[current_device_slot()];
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        attr_set = true;
+    }
+    const int n_cu = device_cus();
+    hipLaunchKernelGGL(k_conv3x3_split_f32, dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+// w: device [256,256,3,3] f32 (a torch conv weight); w_stream: device, 72*2048*16 bytes; transposed = 1 packs the backward-data convolution's weights.
+int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, void* w_stream, void* stream) {
+    if (!w || !w_stream) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    hipLaunchKernelGGL(k_pack_conv_split, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
 }
 
 }  // extern "C"

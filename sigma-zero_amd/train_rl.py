@@ -186,10 +186,23 @@ def loss_fn(model, batch, device):
     return mse + ce, mse, ce
 
 
-def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0):
-    """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce)."""
+def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0, split_convs=False):
+    """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce).
+    split_convs (opt-in, default off = the reference's fp32 arithmetic through torch/MIOpen): the 38 3x3 convolutions of the tower run forward and
+    backward-data on the matrix cores with hi + lo bf16 operands and f32 accumulation (trainconv.py; 4.5e-6 from fp64 per convolution where fp32 is at 5e-7):
+    12.9 -> 9.4 ms per optimiser step at batch 128.  Same loss (1e-4 of the reference's golden values); the whole-network gradient at batch 128 differs from an
+    fp64 step by 1.1e-2 relative L2 where MIOpen's fp32 step differs by 3.4e-3 (39 train-mode BatchNorms amplify any rounding; tools/trainconv_probe.py)."""
     import itertools
     device = device or next(model.parameters()).device
+    if split_convs and not (torch.device(device).type == "cuda" and next(model.parameters()).dtype == torch.float32):
+        split_convs = False
+    if split_convs:
+        from .trainconv import enable_split_convs, disable_split_convs
+        enable_split_convs(model)
+        try:
+            return train(model, dataloader, optimiser, total_steps, lr_scheduler, sync, device, log, start_epoch, split_convs=False)
+        finally:
+            disable_split_convs(model)
     history = []
     model.train()
     n_batches = sync.common_batches(len(dataloader)) if sync is not None else len(dataloader)     # identical on every rank
@@ -257,7 +270,7 @@ def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
     return True
 
 
-def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True):
+def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True, train_convs="torch"):
     """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training.
     fast_inference — the self-play network, fastest first (measured on MI355X at 4096 boards x 800 searches; fidelity = the same 64 positions
     searched with the fp32 module, tests/test_gpu_train_and_precision.py):
@@ -285,7 +298,8 @@ def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync
     games = play_games(player, args, n_games, c960=chess960, max_plies=args.get("max_plies", 100000))
     packed, aidx, aprob, rew = records_from_games(games)
     dl = DeviceBatches(packed, aidx, aprob, rew, batch_size=batch_size, device=device, shuffle=True)       # same batches as DataLoader + collate
-    return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device), games
+    return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device,
+                 split_convs=(train_convs == "split")), games
 
 
 # ----------------------------------------------------------------------------- train_RL.main (:156-275), one process per GPU
@@ -367,6 +381,9 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--log-dir", default="logs", help="per-step loss log logs/RL_train.jsonl (rank 0); empty string = off")
     ap.add_argument("--merge-games", action="store_true", help="concatenate the ranks' game files into the reference's single games/RL_960_{epoch}.pt (small runs)")
+    ap.add_argument("--train-convs", default="torch", choices=["torch", "split"],
+                    help="3x3 convolutions of the train step: torch = MIOpen fp32 (the reference's arithmetic, default); split = the matrix-core kernel on hi+lo bf16 operands "
+                         "(forward + backward-data: 27 %% faster step, same loss, gradient 1e-2 from exact where fp32 is 3e-3)")
     ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split", "fp32"],
                     help="self-play network (run_cycle): fp16 = MFMA tower on f16 operands (default: fp32's visit counts on every tested position, 0.95x of bf16), "
                          "bf16 = fastest (single visits move), split = hi+lo bf16 operands (fp32-class by construction, 0.40x), fp32 = torch module")
@@ -404,7 +421,7 @@ def main(argv=None):
     np.random.seed(1000 + rank)
     for epoch in range(start_epoch, start_epoch + a.epochs):
         hist, games = run_cycle(model, optimiser, sched, args, a.games_per_rank, chess960=bool(a.chess960), sync=sync,
-                                batch_size=a.batch_size, total_steps=a.total_steps, fast_inference=a.inference)
+                                batch_size=a.batch_size, total_steps=a.total_steps, fast_inference=a.inference, train_convs=a.train_convs)
         sync_module_state(model, average_buffers=True) if world > 1 else None
         n_samples = sum(len(g["actions"]) for g in games)
         # games/RL_960_{epoch}.pt (train_RL.py:229-241 merges every worker's games into one file): rank 0 writes its games under the

@@ -1,0 +1,93 @@
+"""The 3x3 convolutions of the RL train step (train_RL.py:103-122 -> network.py:28,30: 38 convolutions 256 -> 256, fp32, forward + backward) on the matrix cores at
+the reference's precision class: hi + lo bf16 operands, three MFMAs per product, f32 accumulation (csrc/sz_nn_split.hip k_conv3x3_split_f32 — the inference tower's
+K loop on one board per workgroup).  MIOpen's fp32 Winograd takes 89 us per convolution at batch 128 (forward and backward-data: 51 % of an optimiser step).
+
+    with split_convs(model):            # or enable_split_convs(model) / disable_split_convs(model)
+        loss, mse, ce = train_rl.loss_fn(model, batch, device); loss.backward()
+
+Forward and backward-data run on the kernel (backward-data = the same convolution of the output gradient with the weights transposed and flipped); the weight gradient
+stays with torch (MIOpen's igemm).  Opt-in (`train_rl.train(..., split_convs=True)`, `run_cycle(train_convs="split")`, `--train-convs split`): the default train step is
+the reference's fp32 arithmetic.  Measured at batch 128 (tools/trainconv_probe.py): optimiser step 12.9 -> 9.4 ms; one convolution 4.5e-6 relative L2 from fp64 (fp32: 5e-7);
+loss unchanged to 1e-4; whole-network gradient 1.1e-2 from an fp64 step where MIOpen's fp32 step is at 3.4e-3 (the 39 train-mode BatchNorms amplify every rounding).
+"""
+import contextlib
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+_STREAM_BYTES = 72 * 2048 * 16
+_scratch = {}
+
+
+def _bufs(dev):
+    key = (dev.type, dev.index)
+    if key not in _scratch:
+        _scratch[key] = (torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev), torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev),
+                         torch.zeros(256, dtype=torch.float32, device=dev))
+    return _scratch[key]
+
+
+def _conv(x, w, transposed):
+    """y = conv3x3(x, w) (transposed: conv3x3(x, w^T flipped)) through the C ABI on x's device and current stream; x [B,256,8,8] f32."""
+    x = x.contiguous()
+    fwd_buf, bwd_buf, zero = _bufs(x.device)
+    buf = bwd_buf if transposed else fwd_buf
+    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), C.c_void_p(buf.data_ptr()), st), "sz_nn_pack_conv_split_dev")
+    y = torch.empty_like(x)
+    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], st),
+            "sz_nn_conv3x3_split_f32")
+    return y
+
+
+class SplitConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _conv(x, w.detach().contiguous(), False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _conv(gy, w.detach().contiguous(), True) if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(x, w.shape, gy.contiguous(), padding=1) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def _eligible(m):
+    return (isinstance(m, torch.nn.Conv2d) and m.in_channels == 256 and m.out_channels == 256 and m.kernel_size == (3, 3) and m.padding == (1, 1)
+            and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None)
+
+
+def enable_split_convs(model):
+    """every 3x3 256->256 convolution of `model` runs SplitConv3x3 on fp32 cuda inputs of 8x8 boards (anything else falls through to torch)"""
+    n = 0
+    for m in model.modules():
+        if _eligible(m) and not hasattr(m, "_sz_orig_forward"):
+            m._sz_orig_forward = m.forward
+
+            def fwd(x, m=m):
+                if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1:] == (256, 8, 8) and m.weight.dtype == torch.float32:
+                    return SplitConv3x3.apply(x, m.weight)
+                return m._sz_orig_forward(x)
+            m.forward = fwd
+            n += 1
+    return n
+
+
+def disable_split_convs(model):
+    for m in model.modules():
+        if hasattr(m, "_sz_orig_forward"):
+            m.forward = m._sz_orig_forward
+            del m._sz_orig_forward
+
+
+@contextlib.contextmanager
+def split_convs(model):
+    enable_split_convs(model)
+    try:
+        yield model
+    finally:
+        disable_split_convs(model)

@@ -54,6 +54,65 @@ def test_train_step_on_the_device_matches_reference_loss_and_the_cpu_step(golden
     assert flipped < 0.01 and rel_d < 0.1, (flipped, rel_d)
 
 
+def test_split_precision_training_convolution_forward_and_backward():
+    """trainconv.SplitConv3x3 (k_conv3x3_split_f32: hi + lo bf16 operands, f32 accumulation) against an fp64 convolution: forward, input gradient (the same
+    kernel with transposed + flipped weights) and weight gradient; fewer boards than CUs, odd counts, more boards than CUs (the persistent board loop)."""
+    import torch.nn.functional as F
+    from sigma_zero_amd.trainconv import SplitConv3x3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = (torch.randn(256, 256, 3, 3, device="cuda", generator=g) * 0.03).requires_grad_()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for B in (1, 37, 300):
+        x = (torch.randn(B, 256, 8, 8, device="cuda", generator=g) * (torch.rand(B, 256, 8, 8, device="cuda", generator=g) < 0.5)).requires_grad_()
+        gy = torch.randn(B, 256, 8, 8, device="cuda", generator=g)
+        y64 = F.conv2d(x.double(), w.double(), padding=1)
+        y64.backward(gy.double())
+        gx64, gw64 = x.grad.clone(), w.grad.clone()
+        x.grad = None; w.grad = None
+        y = SplitConv3x3.apply(x, w)
+        y.backward(gy)
+        assert rel(y, y64) < 2e-5 and rel(x.grad, gx64) < 2e-5 and rel(w.grad, gw64) < 1e-4, (B, rel(y, y64), rel(x.grad, gx64), rel(w.grad, gw64))
+        x.grad = None; w.grad = None
+
+
+def test_train_step_with_split_convolutions_matches_reference_loss_and_the_cpu_gradient(golden_dir):
+    """the opt-in train step with trainconv's split-precision convolutions: loss within 1e-4 of the reference's golden values; the gradient of this 8-sample batch
+    against the CPU's (measured on MI355X: 7.0e-3 relative L2 where MIOpen's fp32 path is at 2.8e-3 — 39 train-mode BatchNorms over 8 samples amplify every rounding)"""
+    from sigma_zero_amd.trainconv import split_convs
+    from sigma_zero_amd import train_rl as T
+    z = np.load(os.path.join(golden_dir, "train_loss_golden.npz"))
+    batch = {"states": torch.from_numpy(z["x"].astype(np.float32)), "actions": torch.from_numpy(z["p_target"]), "rewards": torch.from_numpy(z["v_target"])}
+    grads = {}
+    for kind in ("cpu", "miopen", "split"):
+        dev = "cpu" if kind == "cpu" else "cuda"
+        torch.manual_seed(0)
+        net = sz.policyNN({}).to(dev)
+        net.train()
+        if kind == "split":
+            with split_convs(net):
+                loss, mse, ce = train_rl.loss_fn(net, batch, dev)
+                loss.backward()
+            assert abs(float(mse.detach()) - float(z["mse"])) < 1e-4 and abs(float(ce.detach()) - float(z["ce"])) < 1e-4
+        else:
+            loss, mse, ce = train_rl.loss_fn(net, batch, dev)
+            loss.backward()
+        grads[kind] = torch.cat([p.grad.flatten().cpu() for p in net.parameters()]).double()
+    r_mi = float((grads["miopen"] - grads["cpu"]).norm() / grads["cpu"].norm())
+    r_sp = float((grads["split"] - grads["cpu"]).norm() / grads["cpu"].norm())
+    print("gradient rel L2 vs the CPU's: MIOpen fp32 %.2e, split-precision convolutions %.2e" % (r_mi, r_sp))
+    # train() plumbs the option through and restores the modules' own forward afterwards
+    hist = {}
+    for flag in (False, True):
+        torch.manual_seed(0)
+        net = sz.policyNN({}).cuda()
+        opt, sched = T.make_optimiser(net)
+        dl = [{k: v.cuda() for k, v in batch.items()}] * 3
+        hist[flag] = T.train(net, dl, opt, total_steps=0, lr_scheduler=sched, device="cuda", split_convs=flag)
+        assert not any(hasattr(m, "_sz_orig_forward") for m in net.modules())
+    assert len(hist[True]) == 3 and np.allclose(np.array(hist[True]), np.array(hist[False]), rtol=2e-3, atol=2e-3), (hist[True], hist[False])
+    assert r_sp < 2e-2 and r_mi < 5e-3
+
+
 def test_device_batches_on_the_device_equal_dataloader_with_collate():
     """train_RL.py:14-49 (chessDataset + collatefn) vs DeviceBatches on cuda: the same batches bit for bit"""
     rng = np.random.RandomState(1)

@@ -1,0 +1,62 @@
+"""Training-step convolutions on the split-precision kernel (sigma_zero_amd/trainconv.py) against torch/MIOpen fp32 and an fp64 reference: forward, input gradient,
+whole train step time."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import sigma_zero_amd as sz
+from sigma_zero_amd import train_rl as T
+from sigma_zero_amd.trainconv import SplitConv3x3, split_convs, enable_split_convs
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+x = torch.randn(B, 256, 8, 8, device=dev) * (torch.rand(B, 256, 8, 8, device=dev) < 0.5)
+w = (torch.randn(256, 256, 3, 3, device=dev) * 0.03).requires_grad_()
+gy = torch.randn(B, 256, 8, 8, device=dev)
+xr = x.clone().requires_grad_()
+y64 = F.conv2d(xr.double(), w.double(), padding=1); y64.backward(gy.double())
+gx64 = xr.grad.clone(); gw64 = w.grad.clone(); w.grad = None
+def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
+xr.grad = None
+y32 = F.conv2d(xr, w, padding=1); y32.backward(gy); gx32 = xr.grad.clone(); gw32 = w.grad.clone()
+xr.grad = None; w.grad = None
+ys = SplitConv3x3.apply(xr, w); ys.backward(gy); gxs = xr.grad.clone(); gws = w.grad.clone()
+print("forward   rel L2 vs fp64: torch fp32 %.2e   split kernel %.2e" % (rel(y32, y64), rel(ys, y64)))
+print("grad(x)   rel L2 vs fp64: torch fp32 %.2e   split kernel %.2e" % (rel(gx32, gx64), rel(gxs, gx64)))
+print("grad(w)   rel L2 vs fp64: torch fp32 %.2e   split path (torch wgrad on the same tensors) %.2e" % (rel(gw32, gw64), rel(gws, gw64)))
+def timeit(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
+with torch.no_grad():
+    print("B=%d conv forward: torch %.1f us   split kernel (pack + conv) %.1f us" % (B, timeit(lambda: F.conv2d(x, w, padding=1)), timeit(lambda: SplitConv3x3.apply(x, w))))
+g = torch.Generator(device=dev).manual_seed(1)
+batch = {"states": (torch.rand(128, 119, 8, 8, device=dev, generator=g) < 0.15).float(),
+         "actions": torch.softmax(torch.randn(128, 4672, device=dev, generator=g) * 3, 1), "rewards": torch.randint(-1, 2, (128,), device=dev, generator=g).float()}
+for split in (False, True, False, True):
+    torch.manual_seed(0)
+    model = sz.policyNN({}).to(dev).train()
+    if split: enable_split_convs(model)
+    opt, sched = T.make_optimiser(model)
+    losses = []
+    def step():
+        opt.zero_grad()
+        loss, mse, ce = T.loss_fn(model, batch, dev)
+        loss.backward(); opt.step(); sched.step()
+        losses.append(loss.detach())
+    ms = timeit(step, 30) / 1e3
+    print("train step batch 128, split convs %s: %.2f ms   loss after 35 steps %.6f" % (split, ms, float(losses[-1])))
+# whole-network gradient at batch 128 against an fp64 run of the same step: what each fp32 path loses through 39 train-mode BatchNorms
+def grads(split, dtype):
+    torch.manual_seed(0)
+    model = sz.policyNN({}).to(dev).to(dtype).train()
+    if split: enable_split_convs(model)
+    bb = {k: v.to(dtype) for k, v in batch.items()}
+    loss, mse, ce = T.loss_fn(model, bb, dev)
+    loss.backward()
+    return torch.cat([p.grad.flatten() for p in model.parameters()]).double(), float(loss.detach())
+g64, l64 = grads(False, torch.float64)
+for name, split in (("torch/MIOpen fp32", False), ("split-precision convolutions", True)):
+    g, l = grads(split, torch.float32)
+    print("batch 128 gradient rel L2 vs the fp64 step: %-30s %.2e   (loss %.7f vs %.7f)" % (name, float((g - g64).norm() / g64.norm()), l, l64))
