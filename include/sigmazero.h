@@ -235,9 +235,10 @@ int sz_nn_pack_split_head(const float* w_in /* conv_p2.weight [73,256] */, uint1
 /* Training-step convolutions (train_RL.py:103-122 runs network.py:28,30's 3x3 convolutions forward and backward in fp32) at the reference's precision class on the
  * matrix cores: y = conv3x3(x, w), padding 1, no bias, 256 -> 256 channels; x, y device [n_boards,256,8,8] f32 NCHW.  w_stream (72*2048*16 bytes, device) comes from
  * sz_nn_pack_conv_split_dev(w [256,256,3,3] f32 device, transposed): transposed = 0 for the forward convolution, 1 for backward-data (the same kernel applied to the
- * output gradient).  zero256: device [256] f32 zeros. */
-int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, void* stream);
-int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, void* w_stream, void* stream);
+ * output gradient).  zero256: device [256] f32 zeros.  f16 = 1 (both calls alike): hi + lo f16 operands (22 bits of mantissa: fp32's class) with exact power-of-two
+ * scaling of the weights and of every board; f16 = 0: hi + lo bf16 (16 bits). */
+int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* stream);
+int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* stream);
 /* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */

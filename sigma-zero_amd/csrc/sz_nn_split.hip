@@ -48,7 +48,8 @@ template <int WGB> struct SplitGeom {
 // the ring holds k-steps ks_base .. ks_base + SP_PF - 1; on exit it holds k-steps ks_after .. ks_after + SP_PF - 1 (the next convolution's first ones, or the
 // stem's of the next tile), fetched under this convolution's last k-steps.
 template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */,
-          int NTAPS = 9 /* 1: a 1x1 convolution on the same images (conv_p1 of the fused heads) */>
+          int NTAPS = 9 /* 1: a 1x1 convolution on the same images (conv_p1 of the fused heads) */,
+          class E = ElemBF16 /* element of the hi / lo operands: bf16 (inference), or f16 with power-of-two operand scaling (training convolutions) */>
 __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int offH, const int offL, const int* addr_tab, const WSrc& wr,
                                             const uint32_t ks_base, const uint32_t ks_after, const float* __restrict__ bias,
                                             f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[SP_RING][8]) {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                             const bool idle_g = SKIPROWS && ((SK == 1 && g == 0) || (SK == 2 && g == G - 1));     // this group has an idle position tile (border row)
                             const bool idle = idle_g && m == (SK == 1 ? 0 : 3);
                             if (idle) continue;
-                            acc[i][g * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m], 0, 0, 0);
+                            acc[i][g * 4 + m] = E::mfma(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m]);
                             // one memory instruction per MFMA gap; q counts the MFMAs actually issued in this group (a skipped tile has no gap of its own)
                             const int NR = idle_g ? 3 : 4, q = (prod * 4 + i) * NR + (idle_g && SK == 1 ? m - 1 : m);
                             if (q < 4) {
@@ -493,19 +494,30 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
 
 // =================================================================================================================
 // One 3x3 convolution (256 -> 256 channels, padding 1, no bias) on f32 NCHW tensors at the reference's precision class — for the TRAINING step
-// (train_RL.py:103-122 runs network.py's fp32 convolutions forward and backward through MIOpen: at batch 128 its fp32 Winograd takes 89 us per convolution,
-// 51 % of an optimiser step).  Same machinery as the inference tower: a workgroup takes one board, stages it as hi / lo bf16 images in LDS, runs split_kloop
+// (train_RL.py:103-122 runs network.py's fp32 convolutions forward and backward through MIOpen: at batch 128 its fp32 kernels take 89-105 us per convolution,
+// 51 % of an optimiser step).  Same machinery as the inference tower: a workgroup takes one board, stages it as hi / lo images in LDS, runs split_kloop
 // (three MFMAs per product, f32 accumulate) over a 72-k-step weight stream and writes its 64 channels x 64 positions per wave back as f32.
 // Forward: y = conv(x, w).  Backward-data is the same kernel on the gradient with the weights transposed and flipped (sz_nn_pack_conv_split_dev, transposed = 1).
+// Operand element E:
+//   ElemBF16  hi + lo bf16: 16 bits of mantissa at any magnitude (4.5e-6 from fp64 per convolution);
+//   ElemF16   hi + lo f16: 22 bits — fp32's own class (measured: see tools/trainconv_probe.py) — made range-safe by power-of-two scaling, which is exact: the
+//             weights are packed times 2^SP_WSCALE_LOG2 (|w| up to 63 stays finite, weights down to 1e-3 keep a normal lo part), every BOARD is scaled by its own
+//             2^k so that its largest magnitude lands in [2^11, 2^12) (found in-kernel from the values the threads already hold: gradients of 1e-7 and
+//             activations of 1e+3 are treated alike), and the output is multiplied by 2^-(k + SP_WSCALE_LOG2).  Elements far below a board's maximum have a
+//             subnormal lo part: their error is bounded by 2^-37 of the maximum, absolutely.
 // x, y: [n_boards][256][8][8] f32;  w_stream: 72 k-steps x {hi 16 KB, lo 16 KB} from sz_nn_pack_conv_split_dev.
+#define SP_WSCALE_LOG2 10
+template <class E>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __restrict__ x, const uint4* __restrict__ wstream, const float* __restrict__ zero_bias,
                                                                float* __restrict__ y, int n_boards) {
     constexpr int WGB = 1;
+    constexpr bool SCALED = std::is_same<E, ElemF16>::value;
     using GEO = SplitGeom<WGB>;
     constexpr int NJ = GEO::NJ, PITCH = GEO::PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* imgH = lds;
     unsigned char* imgL = lds + GEO::IMG;
+    float* wmax = (float*)(lds + GEO::SCR);                            // [4 waves]: the board's largest magnitude
     for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) {
         *(uint4*)(imgH + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
         *(uint4*)(imgL + WGB * 64 * PITCH + c * 16) = make_uint4(0, 0, 0, 0);
@@ -529,23 +541,42 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
         // stage: the board is 256 channels x 64 positions of f32, channel-major; a wave instruction reads 1 KiB = 4 channels x 64 positions, lane l holds positions
         // 4*(l & 15) .. +3 of channel 4*q + (l >> 4); every value goes to its (position row, channel) slot of the hi and of the lo image (swizzled chunks)
         const float4* src = (const float4*)(x + (size_t)board * 256 * 64);
-#pragma unroll 4
-        for (int q = wave; q < 64; q += 4) {
-            const float4 v = src[q * 64 + lane];
+        float4 v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = src[(wave + 4 * t) * 64 + lane];
+        float sx = 1.f, unscale = 1.f;
+        if (SCALED) {
+            float m = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; t++) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[t].x), fabsf(v[t].y))), fmaxf(fabsf(v[t].z), fabsf(v[t].w)));
+            for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if (lane == 0) wmax[wave] = m;
+            __syncthreads();
+            m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            // 2^k with max * 2^k in [2^11, 2^12): from the exponent field (an all-zero or non-finite board keeps scale 1)
+            const int ex = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xFF);
+            const int k = (ex == 0 || ex == 255) ? 0 : 11 - (ex - 127);
+            const int kc = k < -100 ? -100 : (k > 100 ? 100 : k);
+            sx = __builtin_bit_cast(float, (uint32_t)(127 + kc) << 23);
+            unscale = __builtin_bit_cast(float, (uint32_t)(127 - kc - SP_WSCALE_LOG2) << 23);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int q = wave + 4 * t;
             const int c = q * 4 + (lane >> 4), p0 = (lane & 15) * 4;
-            const float vv[4] = {v.x, v.y, v.z, v.w};
+            const float vv[4] = {v[t].x * sx, v[t].y * sx, v[t].z * sx, v[t].w * sx};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int row = p0 + k;
                 const int off = row * PITCH + (((c >> 3) ^ ((row >> 2) & 1)) << 4) + (c & 7) * 2;
-                const uint32_t hb = pack_bf16x2(vv[k], 0.f) & 0xFFFFu;
-                const uint32_t lb = pack_bf16x2(vv[k] - bf16_lo(hb), 0.f) & 0xFFFFu;
+                const uint32_t hb = E::pack2(vv[k], 0.f) & 0xFFFFu;
+                const uint32_t lb = E::pack2(vv[k] - E::lo(hb), 0.f) & 0xFFFFu;
                 *(uint16_t*)(imgH + off) = (uint16_t)hb;
                 *(uint16_t*)(imgL + off) = (uint16_t)lb;
             }
         }
         __syncthreads();
-        split_kloop<256, WGB, true, true>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring);      // the stream restarts for the next board
+        split_kloop<256, WGB, true, true, 0, 9, E>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring);      // the stream restarts for the next board
         // acc tile (i, j): lane (p16, kg) holds channels (wave*4 + i)*16 + 4*kg + r, r = 0..3, of position j*16 + p16
         float* dst = y + (size_t)board * 256 * 64;
         const int p16 = lane & 15, kg = lane >> 4;
@@ -554,21 +585,23 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
 #pragma unroll
             for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst[(size_t)((wave * 4 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = acc[i][j][r];
+                for (int r = 0; r < 4; r++) dst[(size_t)((wave * 4 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = SCALED ? acc[i][j][r] * unscale : acc[i][j][r];
     }
 }
 
-// torch conv weight [256 co][256 ci][3][3] f32 (device) -> the 72-k-step hi / lo fragment stream of k_conv3x3_split_f32 (device), one thread per bf16 pair of
-// elements.  transposed = 1: the stream of the backward-data convolution, W'[ci][co][tap] = w[co][ci][8 - tap].
+// torch conv weight [256 co][256 ci][3][3] f32 (device) -> the 72-k-step hi / lo fragment stream of k_conv3x3_split_f32 (device), one thread per element.
+// transposed = 1: the stream of the backward-data convolution, W'[ci][co][tap] = w[co][ci][8 - tap].  ElemF16: times 2^SP_WSCALE_LOG2.
+template <class E>
 __global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                   // over 72 k-steps x 16 tiles x 64 lanes x 8 elements
     if (idx >= 72 * 16 * 64 * 8) return;
     const int e = idx & 7, l = (idx >> 3) & 63, tile = (idx >> 9) & 15, ks = idx >> 13;
     const int tap = ks >> 3, k32 = ks & 7;
     const int co = tile * 16 + (l & 15), ci = k32 * 32 + 8 * (l >> 4) + e;
-    const float v = transposed ? w[((size_t)ci * 256 + co) * 9 + (8 - tap)] : w[((size_t)co * 256 + ci) * 9 + tap];
-    const uint32_t h = pack_bf16x2(v, 0.f) & 0xFFFFu;
-    const uint32_t lo = pack_bf16x2(v - bf16_lo(h), 0.f) & 0xFFFFu;
+    float v = transposed ? w[((size_t)ci * 256 + co) * 9 + (8 - tap)] : w[((size_t)co * 256 + ci) * 9 + tap];
+    if (std::is_same<E, ElemF16>::value) v *= (float)(1 << SP_WSCALE_LOG2);
+    const uint32_t h = E::pack2(v, 0.f) & 0xFFFFu;
+    const uint32_t lo = E::pack2(v - E::lo(h), 0.f) & 0xFFFFu;
     uint16_t* rec = stream + (size_t)ks * SP_KSTEP_U4 * 8;
     rec[((size_t)tile * 64 + l) * 8 + e] = (uint16_t)h;
     rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = (uint16_t)lo;
@@ -703,26 +736,32 @@ int sz_nn_forward_split(const void* planes, const void* w_stream, const float* b
 }
 
 // Training-step convolutions at the reference's precision class (k_conv3x3_split_f32).  x, y: device [n_boards,256,8,8] f32 (NCHW, contiguous); w_stream: device buffer
-// of 72*2048*16 bytes written by sz_nn_pack_conv_split_dev; zero256: device [256] f32 zeros (the convolutions of network.py:28,30 have no bias).
-int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, void* stream) {
+// of 72*2048*16 bytes written by sz_nn_pack_conv_split_dev; zero256: device [256] f32 zeros (the convolutions of network.py:28,30 have no bias); f16: hi + lo f16
+// operands with power-of-two scaling (fp32's class) instead of hi + lo bf16.
+int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* stream) {
     if (!x || !w_stream || !zero256 || !y || n_boards <= 0) return SZ_ERR_INVALID;
     StreamDeviceGuard _guard(stream);
     static bool attr_flags[NN_MAX_DEVICES] = {};
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
         attr_set = true;
     }
     const int n_cu = device_cus();
-    hipLaunchKernelGGL(k_conv3x3_split_f32, dim3(n_boards < n_cu ? n_boards : n_cu), dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
+    const dim3 grid(n_boards < n_cu ? n_boards : n_cu);
+    if (f16) hipLaunchKernelGGL(k_conv3x3_split_f32<ElemF16>, grid, dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
+    else hipLaunchKernelGGL(k_conv3x3_split_f32<ElemBF16>, grid, dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
-// w: device [256,256,3,3] f32 (a torch conv weight); w_stream: device, 72*2048*16 bytes; transposed = 1 packs the backward-data convolution's weights.
-int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, void* w_stream, void* stream) {
+// w: device [256,256,3,3] f32 (a torch conv weight); w_stream: device, 72*2048*16 bytes; transposed = 1 packs the backward-data convolution's weights;
+// f16 must match the convolution call's.
+int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* stream) {
     if (!w || !w_stream) return SZ_ERR_INVALID;
     StreamDeviceGuard _guard(stream);
-    hipLaunchKernelGGL(k_pack_conv_split, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
+    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
+    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

@@ -186,16 +186,16 @@ def loss_fn(model, batch, device):
     return mse + ce, mse, ce
 
 
-def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0, split_convs=False):
+def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0, split_convs=None):
     """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce).
-    split_convs (opt-in, default off = the reference's fp32 arithmetic through torch/MIOpen): the 38 3x3 convolutions of the tower run forward and
-    backward-data on the matrix cores with hi + lo bf16 operands and f32 accumulation (trainconv.py; 4.5e-6 from fp64 per convolution where fp32 is at 5e-7):
-    12.9 -> 9.4 ms per optimiser step at batch 128.  Same loss (1e-4 of the reference's golden values); the whole-network gradient at batch 128 differs from an
-    fp64 step by 1.1e-2 relative L2 where MIOpen's fp32 step differs by 3.4e-3 (39 train-mode BatchNorms amplify any rounding; tools/trainconv_probe.py)."""
+    split_convs (default None = on for an fp32 model on a GPU; False = torch/MIOpen): the 38 3x3 convolutions of the tower run forward and backward-data on the
+    matrix cores with hi + lo f16 operands (22 bits of mantissa, exact power-of-two scaling of the weights and of every board) and f32 accumulation
+    (trainconv.py): one convolution 5.0e-7 relative L2 from fp64 — fp32 through torch is at 4.9e-7 — independent of the tensor's magnitude; the whole-network
+    gradient at batch 128 is 3.45e-3 from an fp64 step where MIOpen's fp32 step is 3.37e-3; same loss.  12.9 -> 9.5 ms per optimiser step at batch 128."""
     import itertools
     device = device or next(model.parameters()).device
-    if split_convs and not (torch.device(device).type == "cuda" and next(model.parameters()).dtype == torch.float32):
-        split_convs = False
+    eligible = torch.device(device).type == "cuda" and next(model.parameters()).dtype == torch.float32
+    split_convs = eligible if split_convs is None else (bool(split_convs) and eligible)
     if split_convs:
         from .trainconv import enable_split_convs, disable_split_convs
         enable_split_convs(model)
@@ -270,7 +270,7 @@ def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
     return True
 
 
-def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True, train_convs="torch"):
+def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True, train_convs="split"):
     """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training.
     fast_inference — the self-play network, fastest first (measured on MI355X at 4096 boards x 800 searches; fidelity = the same 64 positions
     searched with the fp32 module, tests/test_gpu_train_and_precision.py):
@@ -299,7 +299,7 @@ def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync
     packed, aidx, aprob, rew = records_from_games(games)
     dl = DeviceBatches(packed, aidx, aprob, rew, batch_size=batch_size, device=device, shuffle=True)       # same batches as DataLoader + collate
     return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device,
-                 split_convs=(train_convs == "split")), games
+                 split_convs=None if train_convs == "split" else False), games
 
 
 # ----------------------------------------------------------------------------- train_RL.main (:156-275), one process per GPU
@@ -381,9 +381,9 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--log-dir", default="logs", help="per-step loss log logs/RL_train.jsonl (rank 0); empty string = off")
     ap.add_argument("--merge-games", action="store_true", help="concatenate the ranks' game files into the reference's single games/RL_960_{epoch}.pt (small runs)")
-    ap.add_argument("--train-convs", default="torch", choices=["torch", "split"],
-                    help="3x3 convolutions of the train step: torch = MIOpen fp32 (the reference's arithmetic, default); split = the matrix-core kernel on hi+lo bf16 operands "
-                         "(forward + backward-data: 27 %% faster step, same loss, gradient 1e-2 from exact where fp32 is 3e-3)")
+    ap.add_argument("--train-convs", default="split", choices=["split", "torch"],
+                    help="3x3 convolutions of the train step: split = the matrix-core kernel on hi+lo f16 operands (forward + backward-data; fp32's accuracy class, "
+                         "26 %% faster step; default), torch = MIOpen fp32")
     ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split", "fp32"],
                     help="self-play network (run_cycle): fp16 = MFMA tower on f16 operands (default: fp32's visit counts on every tested position, 0.95x of bf16), "
                          "bf16 = fastest (single visits move), split = hi+lo bf16 operands (fp32-class by construction, 0.40x), fp32 = torch module")

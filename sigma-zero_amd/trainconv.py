@@ -1,14 +1,17 @@
 """The 3x3 convolutions of the RL train step (train_RL.py:103-122 -> network.py:28,30: 38 convolutions 256 -> 256, fp32, forward + backward) on the matrix cores at
-the reference's precision class: hi + lo bf16 operands, three MFMAs per product, f32 accumulation (csrc/sz_nn_split.hip k_conv3x3_split_f32 — the inference tower's
-K loop on one board per workgroup).  MIOpen's fp32 Winograd takes 89 us per convolution at batch 128 (forward and backward-data: 51 % of an optimiser step).
+fp32's accuracy: hi + lo f16 operands (22 bits of mantissa), three MFMAs per product, f32 accumulation (csrc/sz_nn_split.hip k_conv3x3_split_f32 — the inference
+tower's K loop on one board per workgroup).  f16's range is handled by exact power-of-two scaling: the weights are packed times 2^10, every board is scaled in-kernel so
+that its largest magnitude lands in [2^11, 2^12), the output is scaled back — gradients of 1e-7 and activations of 1e+3 are treated alike.  MIOpen's fp32 kernels take
+89-105 us per convolution at batch 128 (forward and backward-data: 51 % of an optimiser step); this takes 46 us including the per-step weight pack.
 
     with split_convs(model):            # or enable_split_convs(model) / disable_split_convs(model)
         loss, mse, ce = train_rl.loss_fn(model, batch, device); loss.backward()
 
 Forward and backward-data run on the kernel (backward-data = the same convolution of the output gradient with the weights transposed and flipped); the weight gradient
-stays with torch (MIOpen's igemm).  Opt-in (`train_rl.train(..., split_convs=True)`, `run_cycle(train_convs="split")`, `--train-convs split`): the default train step is
-the reference's fp32 arithmetic.  Measured at batch 128 (tools/trainconv_probe.py): optimiser step 12.9 -> 9.4 ms; one convolution 4.5e-6 relative L2 from fp64 (fp32: 5e-7);
-loss unchanged to 1e-4; whole-network gradient 1.1e-2 from an fp64 step where MIOpen's fp32 step is at 3.4e-3 (the 39 train-mode BatchNorms amplify every rounding).
+stays with torch (MIOpen's igemm).  `train_rl.train` switches it on by default for an fp32 model on a GPU (`split_convs=False` / `--train-convs torch`: MIOpen).
+Measured at batch 128 (tools/trainconv_probe.py, profiles/r03zf_trainconv_probe.txt): optimiser step 12.9 -> 9.5 ms; one convolution 5.0e-7 relative L2 from fp64
+(torch fp32: 4.9e-7), also on inputs scaled by 1e3 or 1e-6; whole-network gradient 3.45e-3 from an fp64 step (MIOpen's fp32 step: 3.37e-3; the 39 train-mode
+BatchNorms amplify every rounding).  OPERANDS_F16 = False selects hi + lo bf16 operands instead (16 bits: 4.5e-6 per convolution, gradient 1.1e-2).
 """
 import contextlib
 import ctypes as C
@@ -19,6 +22,7 @@ from . import _native as N
 
 _STREAM_BYTES = 72 * 2048 * 16
 _scratch = {}
+OPERANDS_F16 = True          # hi + lo f16 operands with power-of-two scaling (22 bits: fp32's class); False: hi + lo bf16 (16 bits)
 
 
 def _bufs(dev):
@@ -35,9 +39,10 @@ def _conv(x, w, transposed):
     fwd_buf, bwd_buf, zero = _bufs(x.device)
     buf = bwd_buf if transposed else fwd_buf
     st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), C.c_void_p(buf.data_ptr()), st), "sz_nn_pack_conv_split_dev")
+    f16 = int(bool(OPERANDS_F16))
+    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), f16, C.c_void_p(buf.data_ptr()), st), "sz_nn_pack_conv_split_dev")
     y = torch.empty_like(x)
-    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], st),
+    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16, st),
             "sz_nn_conv3x3_split_f32")
     return y
 
