@@ -232,6 +232,11 @@ int sz_nn_forward_split(const void* planes, const void* w_stream, const float* b
                         const float* wv, float bv, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* probs, float* value,
                         float* v1_scratch, float* tower_out, int32_t n_boards, int32_t do_softmax, int32_t flags, void* stream);
 int sz_nn_pack_split_head(const float* w_in /* conv_p2.weight [73,256] */, uint16_t* out);
+/* SZ_NN_F16 in `flags` of sz_nn_tower_split / sz_nn_forward_split: hi + lo F16 operands (22 bits of mantissa: fp32's own class, logits 5e-7 from fp64) instead of hi + lo
+ * bf16 (16 bits).  The stream and the head weights then come from the _f16 packers, which multiply the weights by 2^10 (exact; keeps the lo parts of weights down to 1e-3
+ * normal f16 numbers); the caller passes the per-convolution biases (incl. conv_p1's) multiplied by 2^10 as well; the kernels scale every accumulator back. */
+int sz_nn_pack_split_stream_f16(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream);
+int sz_nn_pack_split_head_f16(const float* w_in, uint16_t* out);
 /* Training-step convolutions (train_RL.py:103-122 runs network.py:28,30's 3x3 convolutions forward and backward in fp32) at the reference's precision class on the
  * matrix cores: y = conv3x3(x, w), padding 1, no bias, 256 -> 256 channels; x, y device [n_boards,256,8,8] f32 NCHW.  w_stream (72*2048*16 bytes, device) comes from
  * sz_nn_pack_conv_split_dev(w [256,256,3,3] f32 device, transposed): transposed = 0 for the forward convolution, 1 for backward-data (the same kernel applied to the

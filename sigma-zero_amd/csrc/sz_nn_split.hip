@@ -27,6 +27,7 @@
 #define SP_PF 1                                            // weight prefetch distance in k-steps (1,536 matrix-pipe cycles each with two boards).  -DSP_PF=2 (measured, profiles/r03q_pf.txt):
                                                            // K loop unchanged (108.3k vs 108.4k cycles: the loop does not wait for weights), 30 registers more spilled around the epilogues
 #endif
+#define SP_WSCALE_LOG2 10                                   // f16 operands: the weights are packed times 2^10 (exact), results scaled back
 #ifndef SP_EXPLICIT_WAIT
 #define SP_EXPLICIT_WAIT 1
 #endif
@@ -205,8 +206,11 @@ __device__ __forceinline__ float relu_f32(float v) { const int i = __builtin_bit
 //   MODE 0 (stem)  : x = relu(acc)         -> xres, images
 //   MODE 1 (conv1) : t = relu(acc)         -> images            (network.py:70-72)
 //   MODE 2 (conv2) : x = relu(acc + xres)  -> xres, images      (network.py:74-81; the residual is the exact f32 value, kept in registers)
-template <int WGB, int MODE>
+// E = ElemF16: the weights (and the bias the accumulators started at) were packed times 2^SP_WSCALE_LOG2: the accumulator is scaled back first (exact)
+template <int WGB, int MODE, class E = ElemBF16>
 __device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned char* lo_img, const f32x4 (&acc)[4][4 * WGB], float (&xres)[4][4 * WGB][4]) {
+    constexpr bool SCALED = std::is_same<E, ElemF16>::value;
+    constexpr float USC = 1.0f / (float)(1 << SP_WSCALE_LOG2);
     constexpr int PITCH = NN_COUT * 2 + NN_PAD16;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));                         // opaque per call: the store addresses are not hoisted out of the tile loop (and spilled)
@@ -232,6 +236,7 @@ __device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned c
                 v[d] = acc[ip + d][j];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+                    if (SCALED) v[d][k] *= USC;
                     if (MODE == 2) v[d][k] += r[d][k];
                     v[d][k] = relu_f32(v[d][k]);
                 }
@@ -243,9 +248,9 @@ __device__ __forceinline__ void split_epilogue(unsigned char* hi_img, unsigned c
                     if (MODE != 1) xres[ip + d][j][k] = to_agpr(v[d][k]);
 #pragma unroll
             for (int d = 0; d < 2; d++) {
-                h[d].x = pack_bf16x2(v[d][0], v[d][1]); h[d].y = pack_bf16x2(v[d][2], v[d][3]);
-                l[d].x = pack_bf16x2(v[d][0] - bf16_lo(h[d].x), v[d][1] - bf16_hi(h[d].x));
-                l[d].y = pack_bf16x2(v[d][2] - bf16_lo(h[d].y), v[d][3] - bf16_hi(h[d].y));
+                h[d].x = E::pack2(v[d][0], v[d][1]); h[d].y = E::pack2(v[d][2], v[d][3]);
+                l[d].x = E::pack2(v[d][0] - E::lo(h[d].x), v[d][1] - E::hi(h[d].x));
+                l[d].y = E::pack2(v[d][2] - E::lo(h[d].y), v[d][3] - E::hi(h[d].y));
             }
             // The lane holds 4 channels (8 B) of tile ip and 4 of tile ip + 1; its partner in the neighbouring lane quarter (lane ^ 16) holds the adjacent 4 of each.
             // v_permlane16_swap trades them so that an even quarter ends up with 8 consecutive channels of tile ip and an odd one with 8 of tile ip + 1: one
@@ -279,7 +284,7 @@ struct SplitHeadsParams {
 // Every sum runs in an order that does not depend on the workgroup form: per position over (channel tile, register) in the lane, the two shuffles over
 // the lane's channel quarter, then the 64 positions of the board one after the other from LDS.  So a board's probabilities are the same bit for bit
 // whether it ran alone in a workgroup, beside another board, at batch 1 or 4096 (the self-play records of a game do not depend on the batch it ran in).
-template <int WGB>
+template <int WGB, class E = ElemBF16>
 __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* addr_tab, const WSrc& wr, const uint32_t ks_p1, const float* __restrict__ bias_p1,
                                                  const SplitHeadsParams& hp, f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[SP_RING][8], float (&xres)[4][4 * WGB][4],
                                                  const int board0, const int n_boards) {
@@ -303,18 +308,18 @@ __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* 
             for (int c8 = 0; c8 < 32; c8++) {
                 const uint4 h = *(const uint4*)(ph + ((c8 ^ g) << 4)), l = *(const uint4*)(pl + ((c8 ^ g) << 4));
                 const float4 w0 = ((const float4*)hp.wv)[c8 * 2], w1 = ((const float4*)hp.wv)[c8 * 2 + 1];
-                sv = __builtin_fmaf(w0.x, bf16_lo(h.x) + bf16_lo(l.x), sv); sv = __builtin_fmaf(w0.y, bf16_hi(h.x) + bf16_hi(l.x), sv);
-                sv = __builtin_fmaf(w0.z, bf16_lo(h.y) + bf16_lo(l.y), sv); sv = __builtin_fmaf(w0.w, bf16_hi(h.y) + bf16_hi(l.y), sv);
-                sv = __builtin_fmaf(w1.x, bf16_lo(h.z) + bf16_lo(l.z), sv); sv = __builtin_fmaf(w1.y, bf16_hi(h.z) + bf16_hi(l.z), sv);
-                sv = __builtin_fmaf(w1.z, bf16_lo(h.w) + bf16_lo(l.w), sv); sv = __builtin_fmaf(w1.w, bf16_hi(h.w) + bf16_hi(l.w), sv);
+                sv = __builtin_fmaf(w0.x, E::lo(h.x) + E::lo(l.x), sv); sv = __builtin_fmaf(w0.y, E::hi(h.x) + E::hi(l.x), sv);
+                sv = __builtin_fmaf(w0.z, E::lo(h.y) + E::lo(l.y), sv); sv = __builtin_fmaf(w0.w, E::hi(h.y) + E::hi(l.y), sv);
+                sv = __builtin_fmaf(w1.x, E::lo(h.z) + E::lo(l.z), sv); sv = __builtin_fmaf(w1.y, E::hi(h.z) + E::hi(l.z), sv);
+                sv = __builtin_fmaf(w1.z, E::lo(h.w) + E::lo(l.w), sv); sv = __builtin_fmaf(w1.w, E::hi(h.w) + E::hi(l.w), sv);
             }
             const int board = board0 + (row >> 6);
             if (board < n_boards) hp.v1_out[(size_t)board * 64 + (row & 63)] = fmaxf(sv + hp.bv, 0.f);
         }
     }
-    split_kloop<256, WGB, true, true, 0, 1>(lds, 0, GEO::IMG, addr_tab, wr, ks_p1, 0u, bias_p1, acc, ring);     // fetches the next tile's first stem k-step on its way out
+    split_kloop<256, WGB, true, true, 0, 1, E>(lds, 0, GEO::IMG, addr_tab, wr, ks_p1, 0u, bias_p1, acc, ring);     // fetches the next tile's first stem k-step on its way out
     __syncthreads();                                                   // every wave is done reading x
-    split_epilogue<WGB, 1>(imgH, imgL, acc, xres);                     // t over x
+    split_epilogue<WGB, 1, E>(imgH, imgL, acc, xres);                  // t over x
     __syncthreads();
     // conv_p2: wave w owns position tiles w*NT .. w*NT + NT - 1, all 5 channel tiles; K = 256
     f32x4 pa[5][NT];
@@ -341,7 +346,7 @@ __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* 
             for (int i = 0; i < 5; i++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    pa[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(prod == 1 ? al[i] : ah[i], prod == 2 ? bl[t] : bh[t], pa[i][t], 0, 0, 0);
+                    pa[i][t] = E::mfma(prod == 1 ? al[i] : ah[i], prod == 2 ? bl[t] : bh[t], pa[i][t]);
     }
     __syncthreads();                                                   // every wave is done reading t: the next tile may stage its planes
     // lane holds the logits of positions tile_row(wave*NT + t, p16), channels i*16 + 4*kg + r
@@ -354,6 +359,7 @@ __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* 
             const float bb = co < 73 ? hp.b_p2[co] : 0.f;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
+                if (std::is_same<E, ElemF16>::value) pa[i][t][r] *= 1.0f / (float)(1 << SP_WSCALE_LOG2);       // conv_p2's weights were packed times 2^SP_WSCALE_LOG2
                 pa[i][t][r] += bb;
                 if (co < 73) mx = fmaxf(mx, pa[i][t][r]);
             }
@@ -414,7 +420,9 @@ __device__ __forceinline__ void split_heads_tail(unsigned char* lds, const int* 
 // stamps go to a buffer of their own); 2 / 3 / 4 = stamps + K loop without weight loads / without LDS fragment reads / without both (results garbage)
 #define SPSTAMP(k) do { if (MODE != 0 && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = _t; } } while (0)
 // HEADS: both heads run on the tile at the end (split_heads_tail; hp.probs / hp.v1_out instead of `out`, which may then be NULL)
-template <int WGB, int MODE, bool HEADS>
+// E: operand element — ElemBF16 (hi + lo bf16: 16 bits of mantissa) or ElemF16 (hi + lo f16: 22 bits, fp32's class; weights and biases packed times 2^SP_WSCALE_LOG2 so that
+// the lo parts of weights down to 1e-3 stay normal numbers; activations of this network are O(1) and need no scaling)
+template <int WGB, int MODE, bool HEADS, class E = ElemBF16>
 __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restrict__ planes, const uint4* __restrict__ wstream, const float* __restrict__ bias,
                                                          float* __restrict__ out, int n_boards, int n_blocks, int flags, unsigned long long* __restrict__ stamps,
                                                          const SplitHeadsParams hp) {
@@ -448,34 +456,34 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
         // nobody reads the images here: the previous tile ended with epilogue + barrier, its output went out from registers
-        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16, ElemBF16, true>(imgL, planes, board0, n_boards);
+        if (flags & SZ_NN_IN_BITS) stage_tile_bits<WGB, NN_PAD16, E, true>(imgL, planes, board0, n_boards);
         else stage_tile<128, WGB, NN_PAD16, false, true>(imgL, planes, board0, n_boards, false);
         __syncthreads();
         uint32_t ks = 0;
         const uint32_t ks_p1 = 36u + 72u * (uint32_t)(n_convs - 1);    // conv_p1's 8 k-steps follow the tower's in the stream
         const uint32_t ks_end = HEADS ? ks_p1 : 0u;                    // what the tower's last convolution prefetches: conv_p1, or the next tile's stem
-        split_kloop<128, WGB, false, true>(lds, GEO::IMG, GEO::IMG, addr_tab, wr, ks, n_convs > 1 ? 36u : ks_end, bias, acc, ring);
+        split_kloop<128, WGB, false, true, 0, 9, E>(lds, GEO::IMG, GEO::IMG, addr_tab, wr, ks, n_convs > 1 ? 36u : ks_end, bias, acc, ring);
         ks += 36;
         __syncthreads();                                               // every wave is done reading the planes
-        split_epilogue<WGB, 0>(imgH, imgL, acc, xres);
+        split_epilogue<WGB, 0, E>(imgH, imgL, acc, xres);
         __syncthreads();
         for (int c = 1; c < n_convs; c++) {
             const bool stamp_now = MODE != 0 && (c == 7 || c == 8) && tile == (int)(blockIdx.x + gridDim.x);
             const int sb = (c & 1) ? 0 : 5;
             SPSTAMP(sb + 0);
-            split_kloop<256, WGB, true, true, ABL>(lds, 0, GEO::IMG, addr_tab, wr, ks, c + 1 < n_convs ? ks + 72u : ks_end, bias + c * NN_COUT, acc, ring);
+            split_kloop<256, WGB, true, true, ABL, 9, E>(lds, 0, GEO::IMG, addr_tab, wr, ks, c + 1 < n_convs ? ks + 72u : ks_end, bias + c * NN_COUT, acc, ring);
             ks += 72;
             SPSTAMP(sb + 1);
             __syncthreads();                                           // every wave is done reading the images: they are rewritten in place
             SPSTAMP(sb + 2);
-            if (c & 1) split_epilogue<WGB, 1>(imgH, imgL, acc, xres);
-            else split_epilogue<WGB, 2>(imgH, imgL, acc, xres);
+            if (c & 1) split_epilogue<WGB, 1, E>(imgH, imgL, acc, xres);
+            else split_epilogue<WGB, 2, E>(imgH, imgL, acc, xres);
             SPSTAMP(sb + 3);
             __syncthreads();
             SPSTAMP(sb + 4);
             if (MODE != 0 && stamp_now && c == 8 && (threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
         }
-        if constexpr (HEADS) split_heads_tail<WGB>(lds, addr_tab, wr, ks_p1, bias + n_convs * NN_COUT, hp, acc, ring, xres, board0, n_boards);
+        if constexpr (HEADS) split_heads_tail<WGB, E>(lds, addr_tab, wr, ks_p1, bias + n_convs * NN_COUT, hp, acc, ring, xres, board0, n_boards);
         // tower output straight from the registers (exact f32): lane = 4 channels of one position per tile, 64-byte pieces
         const int p16 = lane & 15, kg = lane >> 4;
         if (!HEADS || out)
@@ -506,7 +514,6 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
 //             activations of 1e+3 are treated alike), and the output is multiplied by 2^-(k + SP_WSCALE_LOG2).  Elements far below a board's maximum have a
 //             subnormal lo part: their error is bounded by 2^-37 of the maximum, absolutely.
 // x, y: [n_boards][256][8][8] f32;  w_stream: 72 k-steps x {hi 16 KB, lo 16 KB} from sz_nn_pack_conv_split_dev.
-#define SP_WSCALE_LOG2 10
 template <class E>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __restrict__ x, const uint4* __restrict__ wstream, const float* __restrict__ zero_bias,
                                                                float* __restrict__ y, int n_boards) {
@@ -628,13 +635,20 @@ int64_t sz_nn_split_stream_elems(int32_t n_blocks) {
 //   stream: the whole stream (sz_nn_split_stream_elems elements); k-step record = 16 co tiles x 64 lanes x 8 bf16 of w_hi, then of w_lo,
 //           fragment order of sz_nn_pack_weights16: lane l, elem e <- w[co = tile*16 + (l&15)][ci = k32*32 + 8*(l>>4) + e]
 //   w_hi = bf16(w) (round to nearest even), w_lo = bf16(w - w_hi)
-int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream) {
+static int pack_split_stream_impl(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream, bool f16);
+int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream) { return pack_split_stream_impl(w_in, cin_real, ksize, conv, stream, false); }
+// the same for the f16-operand kernels (SZ_NN_F16): elements are f16 and the weights are multiplied by 2^10 first (the caller scales the biases alike)
+int sz_nn_pack_split_stream_f16(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream) { return pack_split_stream_impl(w_in, cin_real, ksize, conv, stream, true); }
+}  // extern "C"
+static int pack_split_stream_impl(const float* w_in, int32_t cin_real, int32_t ksize, int32_t conv, uint16_t* stream, bool f16) {
     if (!w_in || !stream || conv < 0 || conv > NN_MAX_CONVS_SPLIT || (ksize != 1 && ksize != 3) || (ksize == 1 && !(conv & 1))) return SZ_ERR_INVALID;
     const int cin_padded = conv == 0 ? 128 : 256, taps = ksize * ksize;
     if (cin_real <= 0 || cin_real > cin_padded) return SZ_ERR_INVALID;
     const int ksteps = cin_padded / 32;
     const size_t ks0 = conv == 0 ? 0 : 36 + (size_t)(conv - 1) * 72;
-    auto rne = [](float v) -> uint16_t { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    const float wscale = f16 ? (float)(1 << SP_WSCALE_LOG2) : 1.f;
+    auto rne = [f16](float v) -> uint16_t { return f16 ? ElemF16::from_float(v) : ElemBF16::from_float(v); };
+    auto back = [f16](uint16_t h) -> float { if (f16) { _Float16 x; memcpy(&x, &h, 2); return (float)x; } const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4); return hf; };
     for (int t = 0; t < taps; t++)
         for (int k = 0; k < ksteps; k++) {
             uint16_t* rec = stream + (ks0 + (size_t)t * ksteps + k) * SP_KSTEP_U4 * 8;
@@ -642,33 +656,39 @@ int sz_nn_pack_split_stream(const float* w_in, int32_t cin_real, int32_t ksize, 
                 for (int l = 0; l < 64; l++)
                     for (int e = 0; e < 8; e++) {
                         const int co = tile * 16 + (l & 15), ci = k * 32 + 8 * (l >> 4) + e;
-                        const float v = ci < cin_real ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f;
+                        const float v = (ci < cin_real ? w_in[((size_t)co * cin_real + ci) * taps + t] : 0.f) * wscale;
                         const uint16_t h = rne(v);
-                        const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
                         rec[((size_t)tile * 64 + l) * 8 + e] = h;
-                        rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = rne(v - hf);
+                        rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = rne(v - back(h));
                     }
         }
     return SZ_OK;
 }
+extern "C" {
 
 // host: conv_p2.weight [73][256] f32 -> [8 k32-steps]{hi: 5 co tiles x 64 lanes x 8, lo: the same} bf16 (channels 73..79 zero), 8*2*5*64*8 elements
-int sz_nn_pack_split_head(const float* w_in, uint16_t* out) {
+static int pack_split_head_impl(const float* w_in, uint16_t* out, bool f16);
+int sz_nn_pack_split_head(const float* w_in, uint16_t* out) { return pack_split_head_impl(w_in, out, false); }
+int sz_nn_pack_split_head_f16(const float* w_in, uint16_t* out) { return pack_split_head_impl(w_in, out, true); }
+}  // extern "C"
+static int pack_split_head_impl(const float* w_in, uint16_t* out, bool f16) {
     if (!w_in || !out) return SZ_ERR_INVALID;
-    auto rne = [](float v) -> uint16_t { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    const float wscale = f16 ? (float)(1 << SP_WSCALE_LOG2) : 1.f;
+    auto rne = [f16](float v) -> uint16_t { return f16 ? ElemF16::from_float(v) : ElemBF16::from_float(v); };
+    auto back = [f16](uint16_t h) -> float { if (f16) { _Float16 x; memcpy(&x, &h, 2); return (float)x; } const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4); return hf; };
     for (int ks = 0; ks < 8; ks++)
         for (int tile = 0; tile < 5; tile++)
             for (int l = 0; l < 64; l++)
                 for (int e = 0; e < 8; e++) {
                     const int co = tile * 16 + (l & 15), ci = ks * 32 + 8 * (l >> 4) + e;
-                    const float v = co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f;
+                    const float v = (co < 73 ? w_in[(size_t)co * 256 + ci] : 0.f) * wscale;
                     const uint16_t h = rne(v);
-                    const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
                     out[((((size_t)ks * 2 + 0) * 5 + tile) * 64 + l) * 8 + e] = h;
-                    out[((((size_t)ks * 2 + 1) * 5 + tile) * 64 + l) * 8 + e] = rne(v - hf);
+                    out[((((size_t)ks * 2 + 1) * 5 + tile) * 64 + l) * 8 + e] = rne(v - back(h));
                 }
     return SZ_OK;
 }
+extern "C" {
 
 }  // extern "C"
 
@@ -681,6 +701,9 @@ static int launch_split(const void* planes, const void* w_stream, const float* b
         SPLIT_ATTR(1, 0, false); SPLIT_ATTR(2, 0, false); SPLIT_ATTR(1, 0, true); SPLIT_ATTR(2, 0, true);
         SPLIT_ATTR(2, 1, false); SPLIT_ATTR(2, 2, false); SPLIT_ATTR(2, 3, false); SPLIT_ATTR(2, 4, false);
 #undef SPLIT_ATTR
+#define SPLIT_ATTR16(W, H) HIPCHK(hipFuncSetAttribute((const void*)k_tower_split<W, 0, H, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<W>::LDS_BYTES))
+        SPLIT_ATTR16(1, false); SPLIT_ATTR16(2, false); SPLIT_ATTR16(1, true); SPLIT_ATTR16(2, true);
+#undef SPLIT_ATTR16
         attr_set = true;
     }
     const int n_cu = device_cus();
@@ -692,7 +715,12 @@ static int launch_split(const void* planes, const void* w_stream, const float* b
     const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
 #define SPLIT_LAUNCH(W, M, H, ST) hipLaunchKernelGGL((k_tower_split<W, M, H>), grid, dim3(256), SplitGeom<W>::LDS_BYTES, (hipStream_t)stream, (const uint16_t*)planes, \
                                                      (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, ST, hp)
-    if (heads) {
+#define SPLIT_LAUNCH16(W, H) hipLaunchKernelGGL((k_tower_split<W, 0, H, ElemF16>), grid, dim3(256), SplitGeom<W>::LDS_BYTES, (hipStream_t)stream, (const uint16_t*)planes, \
+                                                  (const uint4*)w_stream, bias, out, n_boards, n_blocks, (int)flags, (unsigned long long*)nullptr, hp)
+    if (flags & SZ_NN_F16) {
+        if (heads) { if (one) SPLIT_LAUNCH16(1, true); else SPLIT_LAUNCH16(2, true); }
+        else { if (one) SPLIT_LAUNCH16(1, false); else SPLIT_LAUNCH16(2, false); }
+    } else if (heads) {
         if (one) SPLIT_LAUNCH(1, 0, true, (unsigned long long*)nullptr); else SPLIT_LAUNCH(2, 0, true, (unsigned long long*)nullptr);
     } else if (one) SPLIT_LAUNCH(1, 0, false, (unsigned long long*)nullptr);
     else if (!g_split_stamps) SPLIT_LAUNCH(2, 0, false, (unsigned long long*)nullptr);
@@ -701,6 +729,7 @@ static int launch_split(const void* planes, const void* w_stream, const float* b
     else if (g_split_mode == 4) SPLIT_LAUNCH(2, 4, false, g_split_stamps);
     else SPLIT_LAUNCH(2, 1, false, g_split_stamps);
 #undef SPLIT_LAUNCH
+#undef SPLIT_LAUNCH16
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

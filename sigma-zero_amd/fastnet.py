@@ -248,8 +248,12 @@ class SplitPolicyNet:
     on the batch it is evaluated in (bit for bit).  Input: the engine's bit-packed planes ("bits128") or the bf16 NHWC image ("nhwc128").
     The returned tensors are views of buffers that the next call reuses."""
 
-    def __init__(self, model, device=None):
+    def __init__(self, model, device=None, operands="bf16"):
+        """operands: "bf16" (hi + lo bf16: 16 bits of mantissa, logits ~6e-6 from fp64 — reproduces the fp32 network's search results in every test) or
+        "fp16" (hi + lo f16 with the weights scaled by 2^10: 22 bits, logits ~5e-7 = fp32 itself; same MFMA count, the chip holds a ~5 % lower clock)."""
         model = model.eval()
+        assert operands in ("bf16", "fp16")
+        self.operands, self.f16 = operands, operands == "fp16"
         if device is None:
             pdev = next(model.parameters()).device
             device = pdev if pdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
@@ -271,13 +275,15 @@ class SplitPolicyNet:
         for k, (w, b) in enumerate(convs + [(wp1, bp1)]):                  # conv_p1 (1x1) rides behind the tower in the stream: the heads are fused onto the tile
             wk = w.contiguous().cpu().float().numpy()
             assert wk.shape[0] == 256 and wk.shape[2] == wk.shape[3] == (1 if k == len(convs) else 3)
-            N.check(L.sz_nn_pack_split_stream(wk.ctypes.data_as(C.c_void_p), wk.shape[1], wk.shape[2], k, stream.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_stream")
+            N.check((L.sz_nn_pack_split_stream_f16 if self.f16 else L.sz_nn_pack_split_stream)(wk.ctypes.data_as(C.c_void_p), wk.shape[1], wk.shape[2], k,
+                                                                                             stream.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_stream")
         self._wstream = torch.from_numpy(stream.view(np.int16)).to(dev)
-        self._bias = torch.stack([b for _, b in convs] + [bp1]).float().contiguous().to(dev)
+        self._bias = (torch.stack([b for _, b in convs] + [bp1]).float() * (1024.0 if self.f16 else 1.0)).contiguous().to(dev)    # f16 operands: weights and biases times 2^10
+        self._eflag = N.SZ_NN_F16 if self.f16 else 0
         self.force_wgb = 0                                # tests: N.SZ_NN_SPLIT_WGB1 / _WGB2 force one- / two-board workgroups
         wp2 = model.conv_p2.weight.detach().view(73, 256).contiguous().cpu().float().numpy()
         p2 = np.zeros(8 * 2 * 5 * 64 * 8, dtype=np.uint16)
-        N.check(L.sz_nn_pack_split_head(wp2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_head")
+        N.check((L.sz_nn_pack_split_head_f16 if self.f16 else L.sz_nn_pack_split_head)(wp2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p)), "sz_nn_pack_split_head")
         self._wp2 = torch.from_numpy(p2.view(np.int16)).to(dev)
         self.fused_heads = True                           # both heads inside the tower launch (sz_nn_forward_split); False: fp32 GEMM heads through torch (cross-check)
         self._hbuf, self._hcap = None, 0
@@ -311,7 +317,9 @@ class SplitPolicyNet:
         if B > self._cap:
             self._out, self._cap = torch.empty(B, 64, 256, dtype=torch.float32, device=self.device), B
         out = self._out[:B]
-        flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb
+        flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb | self._eflag
+        if self.f16 and planes.dtype == torch.bfloat16:
+            planes = planes.to(torch.float16)
         ev = None
         if self.timing is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -339,7 +347,9 @@ class SplitPolicyNet:
                 self._hcap = B
             policy, value, v1 = (t[:B] for t in self._hbuf)
             P = lambda t: C.c_void_p(t.data_ptr())
-            flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb
+            flags = (N.SZ_NN_IN_BITS if planes.dtype == torch.uint8 else 0) | self.force_wgb | self._eflag
+            if self.f16 and planes.dtype == torch.bfloat16:
+                planes = planes.to(torch.float16)
             ev = None
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -224,6 +224,46 @@ def test_fused_heads_match_separate_head_kernels():
             assert float((v0 - v1).abs().max()) < 1e-5, float((v0 - v1).abs().max())
 
 
+def test_split_precision_network_with_f16_operands_is_as_close_to_fp64_as_fp32_is():
+    """SplitPolicyNet(operands="fp16"): hi + lo f16 operands (22 bits of mantissa; weights and biases times 2^10) — against an fp64 copy of the module, next to the
+    fp32 module itself.  Measured on MI355X: tower activation / centred logits within a factor 2 of fp32's own distance from fp64 (~5e-7), ten times closer than
+    the hi + lo bf16 form; forms and batch composition do not change a bit."""
+    from sigma_zero_amd.fastnet import SplitPolicyNet
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.05); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.05)
+    net64 = sz.policyNN({}).cuda().eval().double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    s16, sb = SplitPolicyNet(net, operands="fp16"), SplitPolicyNet(net)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    c = lambda t: t - t.mean(1, keepdim=True)
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    for B in (1, 37, 300):
+        x = (torch.rand(B, 119, 8, 8, generator=g, device="cuda") < 0.12).float()
+        planes = planes_nchw_to_nhwc128(x)
+        with torch.no_grad():
+            p64, v64 = net64(x.double(), inference=False)
+            p32, v32 = net(x, inference=False)
+            p16, v16 = (t.clone() for t in s16(planes, inference=False))
+            pb, vb = (t.clone() for t in sb(planes, inference=False))
+            e32, e16, eb = rel(c(p32), c(p64)), rel(c(p16), c(p64)), rel(c(pb), c(p64))
+            assert e16 < 3e-6 and e16 < 4 * e32 + 1e-7 and e16 < eb / 3, (e32, e16, eb)
+            assert float((v16.double().view(-1) - v64.view(-1)).abs().max()) < 1e-6
+            s16.force_wgb = N.SZ_NN_SPLIT_WGB1
+            pa, va = (t.clone() for t in s16(planes, inference=True))
+            s16.force_wgb = N.SZ_NN_SPLIT_WGB2
+            pc, vc = (t.clone() for t in s16(planes, inference=True))
+            s16.force_wgb = 0
+            assert torch.equal(pa, pc) and torch.equal(va, vc) and torch.allclose(pa.sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+            y16 = s16.tower(planes).clone()
+            y64 = net64.resnet_blocks(torch.relu(net64.norm_layer(net64.conv1(x.double()))))
+            assert rel(y16.view(B, 8, 8, 256).permute(0, 3, 1, 2), y64) < 3e-6
+    print("split f16x2: centred logits rel L2 vs fp64 %.2e (fp32 module %.2e, split bf16x2 %.2e)" % (e16, e32, eb))
+
+
 def test_fp16_operand_network_matches_fp32_policynn():
     """FastPolicyNet(operands="fp16"): the persistent tower and the fused heads on f16 MFMA operands (11 bits of mantissa; accumulation, bias, residual add in
     f32) against the fp32 module.  Measured on MI355X: tower activation 7.3e-4, centred logits 6.4e-4 relative L2 from fp64 (bf16 operands: 5.8e-3 / 5.1e-3)."""
