@@ -242,7 +242,11 @@ int sz_nn_pack_split_head_f16(const float* w_in, uint16_t* out);
  * sz_nn_pack_conv_split_dev(w [256,256,3,3] f32 device, transposed): transposed = 0 for the forward convolution, 1 for backward-data (the same kernel applied to the
  * output gradient).  zero256: device [256] f32 zeros.  f16 = 1 (both calls alike): hi + lo f16 operands (22 bits of mantissa: fp32's class) with exact power-of-two
  * scaling of the weights and of every board; f16 = 0: hi + lo bf16 (16 bits). */
-int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* stream);
+int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* amax_bits, void* stream);
+/* weight gradient of the same convolution on hi + lo f16 operands: dw[co][ci][tap] = sum_b,pos gy[b][co][pos] * x[b][ci][pos + off(tap)].  amax_gy / amax_x: device uint32
+ * with the f32 bit pattern of max|gy| / max|x| — the optional `amax_bits` output (f16 = 1; atomicMax into a zeroed word) of sz_nn_conv3x3_split_f32 run on those tensors;
+ * part: device scratch, 16*9*256*256 f32; dw: device [256,256,3,3] f32, overwritten. */
+int sz_nn_wgrad3x3_split_f32(const float* gy, const float* x, const void* amax_gy, const void* amax_x, float* part, float* dw, int32_t n_boards, void* stream);
 int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* stream);
 /* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);

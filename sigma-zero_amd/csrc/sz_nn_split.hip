@@ -50,10 +50,11 @@ template <int WGB> struct SplitGeom {
 // stem's of the next tile), fetched under this convolution's last k-steps.
 template <int CIN, int WGB, bool BLO, bool TAB, int ABL = 0 /* timing ablation (diagnostic build): 1 = no weight loads, 2 = no LDS fragment reads in the loop */,
           int NTAPS = 9 /* 1: a 1x1 convolution on the same images (conv_p1 of the fused heads) */,
-          class E = ElemBF16 /* element of the hi / lo operands: bf16 (inference), or f16 with power-of-two operand scaling (training convolutions) */>
+          class E = ElemBF16 /* element of the hi / lo operands: bf16 (inference), or f16 with power-of-two operand scaling (training convolutions) */,
+          int NI = 4 /* channel tiles (16) per wave: 4 = the workgroup covers all 256 output channels; 2 = half of them (training convolution at small batches) */>
 __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int offH, const int offL, const int* addr_tab, const WSrc& wr,
                                             const uint32_t ks_base, const uint32_t ks_after, const float* __restrict__ bias,
-                                            f32x4 (&acc)[4][4 * WGB], uint4 (&ring)[SP_RING][8]) {
+                                            f32x4 (&acc)[NI][4 * WGB], uint4 (&ring)[SP_RING][2 * NI], const int co_tile0 = -1 /* first channel tile of this wave; default wave*NI */) {
     constexpr int PITCH = CIN * 2 + NN_PAD16;
     constexpr int KSTEPS = CIN / 32;
     constexpr int NJ = 4 * WGB, G = WGB;                   // position tiles; groups of 4 tiles per k-step
@@ -61,17 +62,19 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
     constexpr bool SKIPROWS = WGB == 2 && NN_ROWSKIP && NTAPS == 9;
     static_assert(NTAPS == 9 || NTAPS == 1, "3x3 or 1x1");
     static_assert(KSTEPS % SP_RING == 0, "ring slots must be compile-time indices");
+    static_assert(8 + 2 * NI <= NPROD * NI * 3, "every memory instruction needs an MFMA gap of its own");
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));                         // opaque per call: hipcc otherwise hoists the stem's 72 tap addresses out of the tile loop and spills them
     const int wave = threadIdx.x >> 6;
     const int p16 = lane & 15, kg = lane >> 4;
-    const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+    const int ct0 = co_tile0 < 0 ? wave * NI : co_tile0;
+    const uint32_t wlane = (uint32_t)(ct0 * 64 + lane) * 16u;
     {
-        f32x4 binit[4];
+        f32x4 binit[NI];
 #pragma unroll
-        for (int i = 0; i < 4; i++) binit[i] = *(const f32x4*)(bias + (wave * 4 + i) * 16 + 4 * kg);
+        for (int i = 0; i < NI; i++) binit[i] = *(const f32x4*)(bias + (ct0 + i) * 16 + 4 * kg);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) acc[i][j] = binit[i];
     }
@@ -125,8 +128,8 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
 #pragma unroll
                 for (int prod = 0; prod < NPROD; prod++) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][prod == 1 ? 4 + i : i]);
+                    for (int i = 0; i < NI; i++) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][prod == 1 ? NI + i : i]);
 #pragma unroll
                         for (int m = 0; m < 4; m++) {
                             const bool idle_g = SKIPROWS && ((SK == 1 && g == 0) || (SK == 2 && g == G - 1));     // this group has an idle position tile (border row)
@@ -134,7 +137,7 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                             if (idle) continue;
                             acc[i][g * 4 + m] = E::mfma(a, prod == 2 ? bL[m] : bH[buf][m], acc[i][g * 4 + m]);
                             // one memory instruction per MFMA gap; q counts the MFMAs actually issued in this group (a skipped tile has no gap of its own)
-                            const int NR = idle_g ? 3 : 4, q = (prod * 4 + i) * NR + (idle_g && SK == 1 ? m - 1 : m);
+                            const int NR = idle_g ? 3 : 4, q = (prod * NI + i) * NR + (idle_g && SK == 1 ? m - 1 : m);
                             if (q < 4) {
                                 // lo fragments of THIS group (used by its third product, 32 gaps on)
                                 if constexpr (BLO && !(ABL & 2)) {
@@ -152,18 +155,18 @@ __device__ __forceinline__ void split_kloop(const unsigned char* lds, const int 
                                 } else if (tap + 1 < NTAPS) {
                                     if (!(SKIPROWS && mm == 0 && tap + 1 < 3)) bH[buf ^ 1][mm] = LD(abs_addr(bnxt[mm]));
                                 }
-                            } else if (q < 16 && g == 0) {
+                            } else if (q < 8 + 2 * NI && g == 0) {
                                 // weights of the next k-step (this convolution's, the next convolution's, or the next tile's stem)
                                 const int f = q - 8;
-                                if (!(ABL & 1)) ring[(kc + SP_PF) & (SP_RING - 1)][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+                                if (!(ABL & 1)) ring[(kc + SP_PF) & (SP_RING - 1)][f] = ld_wfrag(wr, (size_t)ks_next * SP_KSTEP_U4 + (f >= NI ? SP_KSTEP_U4 / 2 : 0), wlane + (f % NI) * 1024);
                             }
 #if SP_EXPLICIT_WAIT
                             // one explicit wait in a gap that carries no memory instruction, instead of hipcc's counted wait in front of every first use
                             // (sz_nn.hip NN_EXPLICIT_WAIT): before the third product for the lo fragments, at the end of a group for the next group's hi
                             // fragments, at the end of a k-step also for the next k-step's weights (SP_PF - 1 k-steps of 8 loads stay in flight)
-                            if (q == 8 * NR - 1 && NPROD == 3) __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0)
-                            if (q == NPROD * 4 * NR - 1) {
-                                if (g == G - 1) __builtin_amdgcn_s_waitcnt(0x0070 | ((SP_PF - 1) * 8));                            // vmcnt(8 * (SP_PF - 1)) lgkmcnt(0)
+                            if (q == 2 * NI * NR - 1 && NPROD == 3) __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0)
+                            if (q == NPROD * NI * NR - 1) {
+                                if (g == G - 1) __builtin_amdgcn_s_waitcnt(0x0070 | ((SP_PF - 1) * 2 * NI));                       // vmcnt(2*NI * (SP_PF - 1)) lgkmcnt(0)
                                 else __builtin_amdgcn_s_waitcnt(0xC07F);                                                         // lgkmcnt(0)
                             }
 #endif
@@ -514,13 +517,15 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
 //             activations of 1e+3 are treated alike), and the output is multiplied by 2^-(k + SP_WSCALE_LOG2).  Elements far below a board's maximum have a
 //             subnormal lo part: their error is bounded by 2^-37 of the maximum, absolutely.
 // x, y: [n_boards][256][8][8] f32;  w_stream: 72 k-steps x {hi 16 KB, lo 16 KB} from sz_nn_pack_conv_split_dev.
-template <class E>
+// COSPLIT = 2: two workgroups per board, 128 output channels each (batches of at most #CUs / 2 boards: a batch-128 train step would otherwise leave half the chip idle)
+template <class E, int COSPLIT>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __restrict__ x, const uint4* __restrict__ wstream, const float* __restrict__ zero_bias,
-                                                               float* __restrict__ y, int n_boards) {
+                                                               float* __restrict__ y, int n_boards, unsigned int* __restrict__ amax_bits /* optional: atomicMax of the f32 bit
+                                                               pattern of max |x| over the whole tensor (what the weight-gradient kernel scales by) */) {
     constexpr int WGB = 1;
     constexpr bool SCALED = std::is_same<E, ElemF16>::value;
     using GEO = SplitGeom<WGB>;
-    constexpr int NJ = GEO::NJ, PITCH = GEO::PITCH;
+    constexpr int NJ = GEO::NJ, PITCH = GEO::PITCH, NI = 4 / COSPLIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* imgH = lds;
     unsigned char* imgL = lds + GEO::IMG;
@@ -534,16 +539,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
         addr_tab[e] = conv_tap_addr16<PITCH, 9, WGB, true>(e / (NJ * 64), (e >> 6) % NJ, e & 15, (e >> 4) & 3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WSrc wr = wfrag_rsrc(wstream);
-    f32x4 acc[4][NJ];
-    uint4 ring[SP_RING][8];
+    f32x4 acc[NI][NJ];
+    uint4 ring[SP_RING][2 * NI];
+    const int half = COSPLIT == 2 ? (int)(blockIdx.x & 1) : 0, ct0 = half * 8 + wave * NI;      // this wave's first channel tile
     {
-        const uint32_t wlane = (uint32_t)((wave * 4) * 64 + lane) * 16u;
+        const uint32_t wlane = (uint32_t)(ct0 * 64 + lane) * 16u;
 #pragma unroll
         for (int k = 0; k < SP_PF; k++)
 #pragma unroll
-            for (int f = 0; f < 8; f++) ring[k][f] = ld_wfrag(wr, (size_t)k * SP_KSTEP_U4 + (f >= 4 ? SP_KSTEP_U4 / 2 : 0), wlane + (f & 3) * 1024);
+            for (int f = 0; f < 2 * NI; f++) ring[k][f] = ld_wfrag(wr, (size_t)k * SP_KSTEP_U4 + (f >= NI ? SP_KSTEP_U4 / 2 : 0), wlane + (f % NI) * 1024);
     }
-    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    for (int board = blockIdx.x / COSPLIT; board < n_boards; board += gridDim.x / COSPLIT) {
         __syncthreads();                                               // the previous board's images are fully read
         // stage: the board is 256 channels x 64 positions of f32, channel-major; a wave instruction reads 1 KiB = 4 channels x 64 positions, lane l holds positions
         // 4*(l & 15) .. +3 of channel 4*q + (l >> 4); every value goes to its (position row, channel) slot of the hi and of the lo image (swizzled chunks)
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
             if (lane == 0) wmax[wave] = m;
             __syncthreads();
             m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax_bits && threadIdx.x == 0 && half == 0) atomicMax(amax_bits, __builtin_bit_cast(unsigned int, m));
             // 2^k with max * 2^k in [2^11, 2^12): from the exponent field (an all-zero or non-finite board keeps scale 1)
             const int ex = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xFF);
             const int k = (ex == 0 || ex == 255) ? 0 : 11 - (ex - 127);
@@ -583,16 +590,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
             }
         }
         __syncthreads();
-        split_kloop<256, WGB, true, true, 0, 9, E>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring);      // the stream restarts for the next board
+        split_kloop<256, WGB, true, true, 0, 9, E, NI>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring, ct0);      // the stream restarts for the next board
         // acc tile (i, j): lane (p16, kg) holds channels (wave*4 + i)*16 + 4*kg + r, r = 0..3, of position j*16 + p16
         float* dst = y + (size_t)board * 256 * 64;
         const int p16 = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst[(size_t)((wave * 4 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = SCALED ? acc[i][j][r] * unscale : acc[i][j][r];
+                for (int r = 0; r < 4; r++) dst[(size_t)((ct0 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = SCALED ? acc[i][j][r] * unscale : acc[i][j][r];
     }
 }
 
@@ -612,6 +619,141 @@ __global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict
     uint16_t* rec = stream + (size_t)ks * SP_KSTEP_U4 * 8;
     rec[((size_t)tile * 64 + l) * 8 + e] = (uint16_t)h;
     rec[(size_t)SP_KSTEP_U4 * 4 + ((size_t)tile * 64 + l) * 8 + e] = (uint16_t)lo;
+}
+
+// =================================================================================================================
+// Weight gradient of that convolution: dW[co][ci][tap] = sum over boards and positions of gy[b][co][pos] * x[b][ci][pos + off(tap)], on hi + lo f16 operands
+// (three MFMAs per product, f32 accumulate; both tensors scaled by ONE power of two each, taken from the maxima the forward / backward-data kernels left behind).
+// The reduction dimension of the MFMA is the POSITION: a k-step is 32 positions = 4 board rows, a lane's 8 k-elements are one board row.
+//   grid = 4 co blocks x 4 ci blocks x KG board groups; a workgroup accumulates its 64 co x 64 ci x 9 taps over its boards (wave = 2 co tiles x 2 ci tiles x 9 taps:
+//   144 accumulator registers) and writes ONE partial, [KG][tap][co][ci]; k_wgrad_reduce sums the KG partials into dW [co][ci][tap].
+//   gy fragments (A operand, rows = co) come straight from global memory (a lane's 8 floats are contiguous); the x block is staged per board in LDS as f16 hi / lo in
+//   three column-shifted copies (dx = -1, 0, +1) with a zero row above and below, so that every tap's B fragment is one aligned ds_read_b128:
+//   Xs[dx][ci tile][row -1..8][ci 0..15]{hi 16 B, lo 16 B}, row pitch 528 B (slot 2*ci + row: conflict-free for the ds_read_b128 lane groups).
+#define WG_ROWPITCH 528
+#define WG_TILE_BYTES (10 * WG_ROWPITCH)
+#define WG_LDS_BYTES (3 * 4 * WG_TILE_BYTES)
+__device__ __forceinline__ float pow2_from_amax_bits(unsigned int bits, int target_log2, int* k_out) {
+    const int ex = (int)((bits >> 23) & 0xFF);
+    int k = (ex == 0 || ex == 255) ? 0 : target_log2 - (ex - 127);
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    *k_out = k;
+    return __builtin_bit_cast(float, (uint32_t)(127 + k) << 23);
+}
+__global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restrict__ gy, const float* __restrict__ x, const unsigned int* __restrict__ amax_gy,
+                                                            const unsigned int* __restrict__ amax_x, float* __restrict__ part, int n_boards, int KG) {
+    using E = ElemF16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int cob = blockIdx.x & 3, cib = (blockIdx.x >> 2) & 3, kgrp = blockIdx.x >> 4;
+    const int chunk = (n_boards + KG - 1) / KG, b0 = kgrp * chunk, b1 = min(n_boards, b0 + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int n = lane & 15, kg = lane >> 4;
+    int kgy, kx;
+    const float sgy = pow2_from_amax_bits(*amax_gy, 11, &kgy), sx = pow2_from_amax_bits(*amax_x, 11, &kx);
+    const float unscale_g = __builtin_bit_cast(float, (uint32_t)(127 - kgy) << 23), unscale_x = __builtin_bit_cast(float, (uint32_t)(127 - kx) << 23);
+    for (int c = threadIdx.x; c < WG_LDS_BYTES / 16; c += 256) *(uint4*)(lds + c * 16) = make_uint4(0, 0, 0, 0);      // zero rows / edge columns stay zero
+    f32x4 acc[2][2][9];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) acc[a][c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging role: thread -> (ci = tid >> 2 of the block's 64, rows 2q, 2q+1 with q = tid & 3)
+    const int sci = threadIdx.x >> 2, sq = threadIdx.x & 3;
+    const int sbase = (sci >> 4) * WG_TILE_BYTES + (sci & 15) * 32;
+    for (int b = b0; b < b1; b++) {
+        __syncthreads();                                               // the previous board's fragments are read
+        {
+            const float4* src = (const float4*)(x + ((size_t)b * 256 + cib * 64 + sci) * 64 + sq * 16);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            const float rows[2][8] = {{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w}};
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                uint32_t h[8], l[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float sv = rows[rr][c] * sx;
+                    h[c] = E::pack2(sv, 0.f) & 0xFFFFu;
+                    l[c] = E::pack2(sv - E::lo(h[c]), 0.f) & 0xFFFFu;
+                }
+                const int row = 2 * sq + rr + 1;                       // +1: the zero row above
+#pragma unroll
+                for (int dxi = 0; dxi < 3; dxi++) {                    // copy dxi holds x[col + (dxi - 1)] at col
+                    uint32_t ph[4], pl[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c0 = 2 * p + dxi - 1, c1 = c0 + 1;
+                        ph[p] = ((c0 >= 0 && c0 < 8) ? h[c0] : 0u) | (((c1 >= 0 && c1 < 8) ? h[c1] : 0u) << 16);
+                        pl[p] = ((c0 >= 0 && c0 < 8) ? l[c0] : 0u) | (((c1 >= 0 && c1 < 8) ? l[c1] : 0u) << 16);
+                    }
+                    unsigned char* dst = lds + dxi * 4 * WG_TILE_BYTES + sbase + row * WG_ROWPITCH;
+                    *(uint4*)dst = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                    *(uint4*)(dst + 16) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                }
+            }
+        }
+        // A fragments: gy rows of this wave's two co tiles, both k halves
+        bf16x8 ah[2][2], al[2][2];
+#pragma unroll
+        for (int cot = 0; cot < 2; cot++)
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++) {
+                const int co = cob * 64 + (2 * wr + cot) * 16 + n;
+                const float4* g = (const float4*)(gy + ((size_t)b * 256 + co) * 64 + (4 * kh + kg) * 8);
+                const float4 g0 = g[0], g1 = g[1];
+                const float f[8] = {g0.x * sgy, g0.y * sgy, g0.z * sgy, g0.w * sgy, g1.x * sgy, g1.y * sgy, g1.z * sgy, g1.w * sgy};
+                uint32_t hh[4], ll[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    hh[p] = E::pack2(f[2 * p], f[2 * p + 1]);
+                    ll[p] = E::pack2(f[2 * p] - E::lo(hh[p]), f[2 * p + 1] - E::hi(hh[p]));
+                }
+                ah[cot][kh] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+                al[cot][kh] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int cit = 0; cit < 2; cit++)
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const int dy = tap / 3 - 1, dxi = tap % 3;
+                    const unsigned char* src = lds + (dxi * 4 + 2 * wc + cit) * WG_TILE_BYTES + (4 * kh + kg + dy + 1) * WG_ROWPITCH + n * 32;
+                    const bf16x8 bh = *(const bf16x8*)src, bl = *(const bf16x8*)(src + 16);
+#pragma unroll
+                    for (int cot = 0; cot < 2; cot++) {
+                        acc[cot][cit][tap] = E::mfma(ah[cot][kh], bh, acc[cot][cit][tap]);
+                        acc[cot][cit][tap] = E::mfma(al[cot][kh], bh, acc[cot][cit][tap]);
+                        acc[cot][cit][tap] = E::mfma(ah[cot][kh], bl, acc[cot][cit][tap]);
+                    }
+                }
+    }
+    // the partial: [kgrp][tap][co][ci]; D layout: lane column n = ci, rows 4*kg + r = co
+#pragma unroll
+    for (int cot = 0; cot < 2; cot++)
+#pragma unroll
+        for (int cit = 0; cit < 2; cit++)
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int co = cob * 64 + (2 * wr + cot) * 16 + 4 * kg + r, ci = cib * 64 + (2 * wc + cit) * 16 + n;
+                    part[(((size_t)kgrp * 9 + tap) * 256 + co) * 256 + ci] = acc[cot][cit][tap][r] * unscale_g * unscale_x;
+                }
+}
+// dW[co][ci][tap] = sum over the KG partials [kg][tap][co][ci]; one thread per (co, ci)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int KG) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                   // co * 256 + ci
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) s[t] = 0.f;
+    for (int k = 0; k < KG; k++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) s[t] += part[((size_t)k * 9 + t) * 65536 + idx];
+#pragma unroll
+    for (int t = 0; t < 9; t++) dw[(size_t)idx * 9 + t] = s[t];
 }
 
 static unsigned long long* g_split_stamps = nullptr;
@@ -767,20 +909,25 @@ int sz_nn_forward_split(const void* planes, const void* w_stream, const float* b
 // Training-step convolutions at the reference's precision class (k_conv3x3_split_f32).  x, y: device [n_boards,256,8,8] f32 (NCHW, contiguous); w_stream: device buffer
 // of 72*2048*16 bytes written by sz_nn_pack_conv_split_dev; zero256: device [256] f32 zeros (the convolutions of network.py:28,30 have no bias); f16: hi + lo f16
 // operands with power-of-two scaling (fp32's class) instead of hi + lo bf16.
-int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* stream) {
+int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* zero256, float* y, int32_t n_boards, int32_t f16, void* amax_bits, void* stream) {
     if (!x || !w_stream || !zero256 || !y || n_boards <= 0) return SZ_ERR_INVALID;
     StreamDeviceGuard _guard(stream);
     static bool attr_flags[NN_MAX_DEVICES] = {};
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemBF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv3x3_split_f32<ElemF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SplitGeom<1>::LDS_BYTES));
         attr_set = true;
     }
     const int n_cu = device_cus();
-    const dim3 grid(n_boards < n_cu ? n_boards : n_cu);
-    if (f16) hipLaunchKernelGGL(k_conv3x3_split_f32<ElemF16>, grid, dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
-    else hipLaunchKernelGGL(k_conv3x3_split_f32<ElemBF16>, grid, dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards);
+    const bool two = 2 * n_boards <= n_cu;                               // two workgroups per board while that fits in one wave of workgroups
+    const dim3 grid(two ? 2 * n_boards : (n_boards < n_cu ? n_boards : n_cu));
+#define CONV_LAUNCH(E_, CS_, AM_) hipLaunchKernelGGL((k_conv3x3_split_f32<E_, CS_>), grid, dim3(256), SplitGeom<1>::LDS_BYTES, (hipStream_t)stream, x, (const uint4*)w_stream, zero256, y, n_boards, AM_)
+    if (f16) { if (two) CONV_LAUNCH(ElemF16, 2, (unsigned int*)amax_bits); else CONV_LAUNCH(ElemF16, 1, (unsigned int*)amax_bits); }
+    else { if (two) CONV_LAUNCH(ElemBF16, 2, (unsigned int*)nullptr); else CONV_LAUNCH(ElemBF16, 1, (unsigned int*)nullptr); }
+#undef CONV_LAUNCH
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }
@@ -791,6 +938,25 @@ int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, v
     StreamDeviceGuard _guard(stream);
     if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
     else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+
+// Weight gradient of the 3x3 convolution (k_wgrad3x3_split + k_wgrad_reduce): gy, x device [n_boards,256,8,8] f32; amax_gy / amax_x: device uint32 holding the f32 bit
+// pattern of max |gy| / max |x| (left behind by sz_nn_conv3x3_split_f32's amax_bits output on the same tensors); part: device scratch of 16*9*256*256 f32; dw: device
+// [256,256,3,3] f32 (overwritten).
+int sz_nn_wgrad3x3_split_f32(const float* gy, const float* x, const void* amax_gy, const void* amax_x, float* part, float* dw, int32_t n_boards, void* stream) {
+    if (!gy || !x || !amax_gy || !amax_x || !part || !dw || n_boards <= 0) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    static bool attr_flags[NN_MAX_DEVICES] = {};
+    bool& attr_set = attr_flags[current_device_slot()];
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_wgrad3x3_split, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+        attr_set = true;
+    }
+    const int KG = n_boards < 16 ? n_boards : 16;
+    hipLaunchKernelGGL(k_wgrad3x3_split, dim3(16 * KG), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, gy, x, (const unsigned int*)amax_gy, (const unsigned int*)amax_x, part, n_boards, KG);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)part, dw, KG);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

@@ -1,17 +1,21 @@
 """The 3x3 convolutions of the RL train step (train_RL.py:103-122 -> network.py:28,30: 38 convolutions 256 -> 256, fp32, forward + backward) on the matrix cores at
-fp32's accuracy: hi + lo f16 operands (22 bits of mantissa), three MFMAs per product, f32 accumulation (csrc/sz_nn_split.hip k_conv3x3_split_f32 — the inference
-tower's K loop on one board per workgroup).  f16's range is handled by exact power-of-two scaling: the weights are packed times 2^10, every board is scaled in-kernel so
-that its largest magnitude lands in [2^11, 2^12), the output is scaled back — gradients of 1e-7 and activations of 1e+3 are treated alike.  MIOpen's fp32 kernels take
-89-105 us per convolution at batch 128 (forward and backward-data: 51 % of an optimiser step); this takes 46 us including the per-step weight pack.
+fp32's accuracy: hi + lo f16 operands (22 bits of mantissa), three MFMAs per product, f32 accumulation (csrc/sz_nn_split.hip).  f16's range is handled by exact
+power-of-two scaling: the weights are packed times 2^10, every board (forward / backward-data) or the whole tensor (weight gradient) is scaled so that its largest
+magnitude lands in [2^11, 2^12), the output is scaled back — gradients of 1e-7 and activations of 1e+3 are treated alike.
+  forward, backward-data  k_conv3x3_split_f32: the inference tower's K loop, one board per workgroup (two workgroups per board at up to #CUs/2 boards); backward-data is
+                          the same convolution of the output gradient with the weights transposed and flipped; the weights are packed on the device every step;
+  weight gradient         k_wgrad3x3_split + k_wgrad_reduce: the MFMA's reduction dimension is the position (a lane's 8 k-elements = one board row), the x block is
+                          staged per board in LDS in three column-shifted copies, 16 board groups write partial sums that a second kernel adds.
+MIOpen's fp32 kernels take 90-105 us (forward), 216 us (backward) per convolution at batch 128 — 78 % of an optimiser step; these take 42 us and 109 us.
 
     with split_convs(model):            # or enable_split_convs(model) / disable_split_convs(model)
         loss, mse, ce = train_rl.loss_fn(model, batch, device); loss.backward()
 
-Forward and backward-data run on the kernel (backward-data = the same convolution of the output gradient with the weights transposed and flipped); the weight gradient
-stays with torch (MIOpen's igemm).  `train_rl.train` switches it on by default for an fp32 model on a GPU (`split_convs=False` / `--train-convs torch`: MIOpen).
-Measured at batch 128 (tools/trainconv_probe.py, profiles/r03zf_trainconv_probe.txt): optimiser step 12.9 -> 9.5 ms; one convolution 5.0e-7 relative L2 from fp64
-(torch fp32: 4.9e-7), also on inputs scaled by 1e3 or 1e-6; whole-network gradient 3.45e-3 from an fp64 step (MIOpen's fp32 step: 3.37e-3; the 39 train-mode
-BatchNorms amplify every rounding).  OPERANDS_F16 = False selects hi + lo bf16 operands instead (16 bits: 4.5e-6 per convolution, gradient 1.1e-2).
+`train_rl.train` switches it on by default for an fp32 model on a GPU (`split_convs=False` / `--train-convs torch`: MIOpen).  Measured at batch 128
+(tools/trainconv_probe.py, profiles/r03zm_trainconv_probe.txt): optimiser step 12.9 -> 8.0-8.6 ms; forward / input gradient / weight gradient of one convolution
+5.0e-7 / 5.1e-7 / 2.7e-7 relative L2 from fp64 (torch fp32: 4.9e-7 / 5.1e-7 / 2.5e-7), also on inputs scaled by 1e3 or 1e-6; whole-network gradient 3.45e-3 from an fp64
+step (MIOpen's fp32 step: 3.37e-3; the 39 train-mode BatchNorms amplify every rounding).  OPERANDS_F16 = False selects hi + lo bf16 operands for forward / backward-data
+(16 bits: 4.5e-6 per convolution, gradient 1.1e-2) with torch's weight gradient; WGRAD_KERNEL = False keeps torch's weight gradient.
 """
 import contextlib
 import ctypes as C
@@ -29,35 +33,65 @@ def _bufs(dev):
     key = (dev.type, dev.index)
     if key not in _scratch:
         _scratch[key] = (torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev), torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev),
-                         torch.zeros(256, dtype=torch.float32, device=dev))
+                         torch.zeros(256, dtype=torch.float32, device=dev), torch.empty(16 * 9 * 256 * 256, dtype=torch.float32, device=dev))
     return _scratch[key]
 
 
-def _conv(x, w, transposed):
-    """y = conv3x3(x, w) (transposed: conv3x3(x, w^T flipped)) through the C ABI on x's device and current stream; x [B,256,8,8] f32."""
+def _conv(x, w, transposed, amax=None):
+    """y = conv3x3(x, w) (transposed: conv3x3(x, w^T flipped)) through the C ABI on x's device and current stream; x [B,256,8,8] f32.
+    amax: optional zeroed int32[1] device tensor that receives the bit pattern of max |x| (f16 operands only)."""
     x = x.contiguous()
-    fwd_buf, bwd_buf, zero = _bufs(x.device)
+    fwd_buf, bwd_buf, zero, _ = _bufs(x.device)
     buf = bwd_buf if transposed else fwd_buf
     st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     f16 = int(bool(OPERANDS_F16))
     N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), f16, C.c_void_p(buf.data_ptr()), st), "sz_nn_pack_conv_split_dev")
     y = torch.empty_like(x)
-    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16, st),
-            "sz_nn_conv3x3_split_f32")
+    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16,
+                                            C.c_void_p(amax.data_ptr()) if (amax is not None and f16) else None, st), "sz_nn_conv3x3_split_f32")
     return y
+
+
+def _wgrad(gy, x, amax_gy, amax_x, wshape):
+    """dW of the convolution on hi + lo f16 operands (k_wgrad3x3_split + reduce); the two maxima are the side outputs of the forward / backward-data kernels"""
+    gy, x = gy.contiguous(), x.contiguous()
+    part = _bufs(x.device)[3]
+    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    N.check(N.lib().sz_nn_wgrad3x3_split_f32(C.c_void_p(gy.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(amax_gy.data_ptr()), C.c_void_p(amax_x.data_ptr()),
+                                             C.c_void_p(part.data_ptr()), C.c_void_p(dw.data_ptr()), x.shape[0], st), "sz_nn_wgrad3x3_split_f32")
+    return dw
+
+
+WGRAD_KERNEL = True          # the weight gradient on the matrix cores too (f16 operands only); False: torch.nn.grad.conv2d_weight (MIOpen)
 
 
 class SplitConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return _conv(x, w.detach().contiguous(), False)
+        use_wg = bool(WGRAD_KERNEL and OPERANDS_F16)
+        amax_x = torch.zeros(1, dtype=torch.int32, device=x.device) if use_wg else None
+        ctx.save_for_backward(x, w, amax_x) if use_wg else ctx.save_for_backward(x, w)
+        ctx.use_wg = use_wg
+        return _conv(x, w.detach().contiguous(), False, amax_x)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gx = _conv(gy, w.detach().contiguous(), True) if ctx.needs_input_grad[0] else None
-        gw = torch.nn.grad.conv2d_weight(x, w.shape, gy.contiguous(), padding=1) if ctx.needs_input_grad[1] else None
+        if ctx.use_wg:
+            x, w, amax_x = ctx.saved_tensors
+        else:
+            x, w = ctx.saved_tensors
+        gx = gw = None
+        amax_gy = torch.zeros(1, dtype=torch.int32, device=gy.device) if (ctx.use_wg and ctx.needs_input_grad[1]) else None
+        if ctx.needs_input_grad[0]:
+            gx = _conv(gy, w.detach().contiguous(), True, amax_gy)
+        if ctx.needs_input_grad[1]:
+            if ctx.use_wg:
+                if not ctx.needs_input_grad[0]:                    # no backward-data kernel ran: take the maximum with torch
+                    amax_gy = gy.detach().abs().amax().reshape(1).view(torch.int32)
+                gw = _wgrad(gy, x, amax_gy, amax_x, w.shape)
+            else:
+                gw = torch.nn.grad.conv2d_weight(x, w.shape, gy.contiguous(), padding=1)
         return gx, gw
 
 

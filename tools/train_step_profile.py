@@ -23,6 +23,9 @@ def timeit(step, n=30):
 
 if mode in ("eager", "both"):
     model = sz.policyNN({}).to(dev).train()
+    if os.environ.get("SZ_TRAINCONVS", "0") == "1":        # the default train step of train_rl: the tower's convolutions on the matrix cores (trainconv.py)
+        from sigma_zero_amd.trainconv import enable_split_convs
+        enable_split_convs(model)
     opt, sched = T.make_optimiser(model)
     def step():
         opt.zero_grad()

@@ -27,6 +27,7 @@ for f16 in (True, False):
     print("operands %s:" % ("hi+lo f16, scaled" if f16 else "hi+lo bf16"))
     print("  forward   rel L2 vs fp64: torch fp32 %.2e   split kernel %.2e" % (rel(y32, y64), rel(ys, y64)))
     print("  grad(x)   rel L2 vs fp64: torch fp32 %.2e   split kernel %.2e" % (rel(gx32, gx64), rel(gxs, gx64)))
+    print("  grad(w)   rel L2 vs fp64: torch fp32 %.2e   %s %.2e" % (rel(gw32, gw64), "wgrad kernel" if f16 else "torch wgrad", rel(gws, gw64)))
     # the same with tiny gradients and large activations: the per-board scaling must not care
     with torch.no_grad():
         print("  forward on x*1e3 %.2e   on x*1e-6 %.2e   (rel L2 vs fp64)" % (rel(SplitConv3x3.apply(x * 1e3, w), y64 * 1e3), rel(SplitConv3x3.apply(x * 1e-6, w), y64 * 1e-6)))
@@ -36,6 +37,14 @@ def timeit(fn, n=50):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
+def bwd_time(fn_conv):
+    xx = x.clone().requires_grad_(); ww = w.detach().clone().requires_grad_()
+    yy = fn_conv(xx, ww)
+    def f():
+        xx.grad = None; ww.grad = None
+        yy.backward(gy, retain_graph=True)
+    return timeit(f)
+print("B=%d conv backward (grad x + grad w): torch %.1f us   split kernels %.1f us" % (B, bwd_time(lambda a, b: F.conv2d(a, b, padding=1)), bwd_time(SplitConv3x3.apply)))
 with torch.no_grad():
     print("B=%d conv forward: torch %.1f us   split kernel (pack + conv) %.1f us" % (B, timeit(lambda: F.conv2d(x, w, padding=1)), timeit(lambda: SplitConv3x3.apply(x, w))))
 g = torch.Generator(device=dev).manual_seed(1)
