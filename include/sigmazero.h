@@ -247,7 +247,7 @@ int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* z
  * with the f32 bit pattern of max|gy| / max|x| — the optional `amax_bits` output (f16 = 1; atomicMax into a zeroed word) of sz_nn_conv3x3_split_f32 run on those tensors;
  * part: device scratch, 16*9*256*256 f32; dw: device [256,256,3,3] f32, overwritten. */
 int sz_nn_wgrad3x3_split_f32(const float* gy, const float* x, const void* amax_gy, const void* amax_x, float* part, float* dw, int32_t n_boards, void* stream);
-int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* stream);
+int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* zero_u32 /* optional: device uint32 set to 0 = the amax_bits slot of the convolution that follows */, void* stream);
 /* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */

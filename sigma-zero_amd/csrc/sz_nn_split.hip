@@ -606,9 +606,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
 // torch conv weight [256 co][256 ci][3][3] f32 (device) -> the 72-k-step hi / lo fragment stream of k_conv3x3_split_f32 (device), one thread per element.
 // transposed = 1: the stream of the backward-data convolution, W'[ci][co][tap] = w[co][ci][8 - tap].  ElemF16: times 2^SP_WSCALE_LOG2.
 template <class E>
-__global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed) {
+__global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed, unsigned int* __restrict__ zero_u32) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                   // over 72 k-steps x 16 tiles x 64 lanes x 8 elements
     if (idx >= 72 * 16 * 64 * 8) return;
+    if (zero_u32 && idx == 0) *zero_u32 = 0u;                         // the maximum slot of the convolution that follows on this stream
     const int e = idx & 7, l = (idx >> 3) & 63, tile = (idx >> 9) & 15, ks = idx >> 13;
     const int tap = ks >> 3, k32 = ks & 7;
     const int co = tile * 16 + (l & 15), ci = k32 * 32 + 8 * (l >> 4) + e;
@@ -932,12 +933,12 @@ int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* z
     return SZ_OK;
 }
 // w: device [256,256,3,3] f32 (a torch conv weight); w_stream: device, 72*2048*16 bytes; transposed = 1 packs the backward-data convolution's weights;
-// f16 must match the convolution call's.
-int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* stream) {
+// f16 must match the convolution call's; zero_u32: optional device uint32 set to 0 (the amax_bits slot of the convolution that follows on the same stream).
+int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* zero_u32, void* stream) {
     if (!w || !w_stream) return SZ_ERR_INVALID;
     StreamDeviceGuard _guard(stream);
-    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
-    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed);
+    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32);
+    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

@@ -39,16 +39,17 @@ def _bufs(dev):
 
 def _conv(x, w, transposed, amax=None):
     """y = conv3x3(x, w) (transposed: conv3x3(x, w^T flipped)) through the C ABI on x's device and current stream; x [B,256,8,8] f32.
-    amax: optional zeroed int32[1] device tensor that receives the bit pattern of max |x| (f16 operands only)."""
+    amax: optional int32[1] device tensor that receives the bit pattern of max |x| (f16 operands only; the pack kernel zeroes it first)."""
     x = x.contiguous()
     fwd_buf, bwd_buf, zero, _ = _bufs(x.device)
     buf = bwd_buf if transposed else fwd_buf
     st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     f16 = int(bool(OPERANDS_F16))
-    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), f16, C.c_void_p(buf.data_ptr()), st), "sz_nn_pack_conv_split_dev")
+    amax_p = C.c_void_p(amax.data_ptr()) if (amax is not None and f16) else None
+    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), f16, C.c_void_p(buf.data_ptr()), amax_p, st), "sz_nn_pack_conv_split_dev")
     y = torch.empty_like(x)
     N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16,
-                                            C.c_void_p(amax.data_ptr()) if (amax is not None and f16) else None, st), "sz_nn_conv3x3_split_f32")
+                                            amax_p, st), "sz_nn_conv3x3_split_f32")
     return y
 
 
@@ -70,7 +71,7 @@ class SplitConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         use_wg = bool(WGRAD_KERNEL and OPERANDS_F16)
-        amax_x = torch.zeros(1, dtype=torch.int32, device=x.device) if use_wg else None
+        amax_x = torch.empty(1, dtype=torch.int32, device=x.device) if use_wg else None
         ctx.save_for_backward(x, w, amax_x) if use_wg else ctx.save_for_backward(x, w)
         ctx.use_wg = use_wg
         return _conv(x, w.detach().contiguous(), False, amax_x)
@@ -82,7 +83,7 @@ class SplitConv3x3(torch.autograd.Function):
         else:
             x, w = ctx.saved_tensors
         gx = gw = None
-        amax_gy = torch.zeros(1, dtype=torch.int32, device=gy.device) if (ctx.use_wg and ctx.needs_input_grad[1]) else None
+        amax_gy = torch.empty(1, dtype=torch.int32, device=gy.device) if (ctx.use_wg and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[0]:
             gx = _conv(gy, w.detach().contiguous(), True, amax_gy)
         if ctx.needs_input_grad[1]:
