@@ -176,6 +176,14 @@ class GradSync:
     def zero(self):
         self.flat.zero_()
 
+    def reduce_all(self):
+        """All buckets at once, after a backward that ran without the hooks (a replayed HIP graph: train(graph=True))."""
+        if self.collective:
+            for h in [self.dist.all_reduce(self.flat[blo:bhi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for blo, bhi in self.buckets]:
+                h.wait()
+            if self.world > 1:
+                self.flat.div_(self.world)
+
 
 # ----------------------------------------------------------------------------- training
 def loss_fn(model, batch, device):
@@ -186,37 +194,111 @@ def loss_fn(model, batch, device):
     return mse + ce, mse, ce
 
 
-def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0, split_convs=None):
+class GraphedStep:
+    """Gradient zeroing + forward + backward of one optimiser step as ONE HIP-graph replay (train(graph=True); opt-in).  With the convolutions on the matrix cores a
+    step is 7.2 ms of kernels in ~1,100 launches, which a host issues in 6-10 ms: on a slow host the eager loop is host-bound (tools/train_loop_probe.py), the replay
+    (7.6-8.0 ms) is not.  The first WARMUP steps run eagerly on
+    the capture stream (real steps: nothing is computed twice), the second one is then captured with static batch buffers; every later batch of the same shape is copied
+    in and replayed; a batch of another shape drops the graph (eager steps, then a new capture).  Gradients are static tensors (GradSync's flat buffer, or per-parameter tensors allocated here) zeroed inside the
+    graph; the optimiser step, the learning-rate schedule and the gradient all-reduce stay outside."""
+    WARMUP = 2
+
+    def __init__(self, model, device, sync=None):
+        self.model, self.device, self.sync = model, torch.device(device), sync
+        self.graph, self.static, self.out, self.seen = None, None, None, 0
+        self.side = torch.cuda.Stream(self.device)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if sync is None:
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+        self.grads = [p.grad for p in self.params]
+
+    def _zero(self):
+        if self.sync is not None:
+            self.sync.zero()
+        else:
+            torch._foreach_zero_(self.grads)
+
+    def _forward_backward(self, batch):
+        self._zero()
+        loss, mse, ce = loss_fn(self.model, batch, self.device)
+        loss.backward()
+        return mse.detach(), ce.detach()
+
+    def step(self, batch):
+        """-> (mse, ce) device scalars of this batch; the gradients are in place when it returns (ordered on the current stream)."""
+        b = {k: batch[k].to(self.device) for k in ("states", "actions", "rewards")}
+        if self.graph is not None and all(b[k].shape == self.static[k].shape and b[k].dtype == self.static[k].dtype for k in b):
+            for k in b:
+                self.static[k].copy_(b[k])
+            self.graph.replay()
+            return self.out
+        if self.graph is not None:
+            # A batch of another shape: the graph is dropped and captured again two steps later.  (Keeping it does not work on ROCm 7.2: the first eager step of a shape
+            # the process has not run before — MIOpen loads kernels for it — leaves every later replay of an EXISTING graph with a wrong multi-block reduction (the
+            # cross-entropy sum comes out as one block's partial; everything else, gradients included, stays right); a graph captured afterwards is fine.
+            # tests/test_gpu_round3.py holds the case.)
+            self.graph, self.static, self.out, self.seen = None, None, None, 0
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            out = self._forward_backward(b)
+        cur.wait_stream(self.side)
+        self.seen += 1
+        if self.graph is None and self.seen >= self.WARMUP:
+            self.static = {k: v.clone() for k, v in b.items()}
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self.side):
+                self.out = self._forward_backward(self.static)
+            self.graph = graph
+        return out
+
+
+def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=None, device=None, log=None, start_epoch=0, split_convs=None, graph=False):
     """train() of train_RL.py:77-154 without the test()/checkpoint side effects; returns the list of (mse, ce).
-    split_convs (default None = on for an fp32 model on a GPU; False = torch/MIOpen): the 38 3x3 convolutions of the tower run forward and backward-data on the
-    matrix cores with hi + lo f16 operands (22 bits of mantissa, exact power-of-two scaling of the weights and of every board) and f32 accumulation
-    (trainconv.py): one convolution 5.0e-7 relative L2 from fp64 — fp32 through torch is at 4.9e-7 — independent of the tensor's magnitude; the whole-network
-    gradient at batch 128 is 3.45e-3 from an fp64 step where MIOpen's fp32 step is 3.37e-3; same loss.  12.9 -> 9.5 ms per optimiser step at batch 128."""
+    split_convs (default None = on for an fp32 model on a GPU; False = torch/MIOpen): the 38 3x3 convolutions of the tower run forward, backward-data and weight
+    gradient on the matrix cores with hi + lo f16 operands (22 bits of mantissa, exact power-of-two scaling) and f32 accumulation (trainconv.py): one convolution
+    5.0e-7 relative L2 from fp64 — fp32 through torch is at 4.9e-7 — independent of the tensor's magnitude; the whole-network gradient at batch 128 is 3.45e-3 from an
+    fp64 step where MIOpen's fp32 step is 3.37e-3; same loss.  12.9 -> 7.3-8.6 ms per optimiser step at batch 128 (host-bound when eager).
+    graph (default False): True = gradient zeroing + forward + backward as one HIP-graph replay per step (GraphedStep): the same kernels on the same data, issued by
+    one call.  Off by default because it does not pay on a host that keeps up: with the matrix-core convolutions a step is 7.2 ms of kernels and a fast host issues
+    them in 6.0-7.1 ms, so eager is GPU-bound at 7.25-7.7 ms where the replay takes 7.6-8.0 ms (profiles/r03zt_train_loop_probe.txt, r03zu_cycle_graph_ab.txt); it is
+    the switch for a slow or contended host (8-10 ms eager).  With several ranks graph=True reduces all gradient buckets after the replay instead of overlapping them
+    with backward from hooks."""
     import itertools
     device = device or next(model.parameters()).device
-    eligible = torch.device(device).type == "cuda" and next(model.parameters()).dtype == torch.float32
+    on_gpu = torch.device(device).type == "cuda"
+    eligible = on_gpu and next(model.parameters()).dtype == torch.float32
     split_convs = eligible if split_convs is None else (bool(split_convs) and eligible)
     if split_convs:
         from .trainconv import enable_split_convs, disable_split_convs
         enable_split_convs(model)
         try:
-            return train(model, dataloader, optimiser, total_steps, lr_scheduler, sync, device, log, start_epoch, split_convs=False)
+            return train(model, dataloader, optimiser, total_steps, lr_scheduler, sync, device, log, start_epoch, split_convs=False, graph=graph)
         finally:
             disable_split_convs(model)
+    graph = bool(graph) and on_gpu
     history = []
     model.train()
     n_batches = sync.common_batches(len(dataloader)) if sync is not None else len(dataloader)     # identical on every rank
+    graphed = GraphedStep(model, device, sync) if graph else None
     for step in range(start_epoch, total_steps + 1):
         for batch in itertools.islice(iter(dataloader), n_batches):
-            if sync is not None:
-                sync.zero()
-                sync.begin_step()
+            if graphed is not None:
+                mse, ce = graphed.step(batch)
+                if sync is not None:
+                    sync.reduce_all()
             else:
-                optimiser.zero_grad()
-            loss, mse, ce = loss_fn(model, batch, device)
-            loss.backward()
-            if sync is not None:
-                sync.finish_step()
+                if sync is not None:
+                    sync.zero()
+                    sync.begin_step()
+                else:
+                    optimiser.zero_grad()
+                loss, mse, ce = loss_fn(model, batch, device)
+                loss.backward()
+                if sync is not None:
+                    sync.finish_step()
             optimiser.step()
             if lr_scheduler is not None:
                 lr_scheduler.step()
@@ -270,7 +352,7 @@ def load_cycle(model, optimiser, cycle, out_dir="saves", device=None):
     return True
 
 
-def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True, train_convs="split"):
+def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync=None, batch_size=128, total_steps=6, fast_inference=True, train_convs="split", train_graph=False):
     """One epoch of train_RL.main (:205-264) on this rank: self-play n_games on this GPU, then 7 passes of training.
     fast_inference — the self-play network, fastest first (measured on MI355X at 4096 boards x 800 searches; fidelity = the same 64 positions
     searched with the fp32 module, tests/test_gpu_train_and_precision.py):
@@ -299,7 +381,7 @@ def run_cycle(model, optimiser, lr_scheduler, args, n_games, chess960=True, sync
     packed, aidx, aprob, rew = records_from_games(games)
     dl = DeviceBatches(packed, aidx, aprob, rew, batch_size=batch_size, device=device, shuffle=True)       # same batches as DataLoader + collate
     return train(model, dl, optimiser, total_steps=total_steps, lr_scheduler=lr_scheduler, sync=sync, device=device,
-                 split_convs=None if train_convs == "split" else False), games
+                 split_convs=None if train_convs == "split" else False, graph=train_graph), games
 
 
 # ----------------------------------------------------------------------------- train_RL.main (:156-275), one process per GPU
@@ -382,8 +464,11 @@ def main(argv=None):
     ap.add_argument("--log-dir", default="logs", help="per-step loss log logs/RL_train.jsonl (rank 0); empty string = off")
     ap.add_argument("--merge-games", action="store_true", help="concatenate the ranks' game files into the reference's single games/RL_960_{epoch}.pt (small runs)")
     ap.add_argument("--train-convs", default="split", choices=["split", "torch"],
-                    help="3x3 convolutions of the train step: split = the matrix-core kernel on hi+lo f16 operands (forward + backward-data; fp32's accuracy class, "
-                         "26 %% faster step; default), torch = MIOpen fp32")
+                    help="3x3 convolutions of the train step: split = the matrix-core kernels on hi+lo f16 operands (forward, backward-data, weight gradient; fp32's "
+                         "accuracy class, 35-45 %% faster step; default), torch = MIOpen fp32")
+    ap.add_argument("--train-graph", default="off", choices=["on", "off"],
+                    help="gradient zeroing + forward + backward of a step as one HIP-graph replay: makes the step independent of the host's launch rate (7.6-8.0 ms); "
+                         "off by default, a host that keeps up runs the eager loop GPU-bound at 7.3-7.7 ms")
     ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split", "fp32"],
                     help="self-play network (run_cycle): fp16 = MFMA tower on f16 operands (default: fp32's visit counts on every tested position, 0.95x of bf16), "
                          "bf16 = fastest (single visits move), split = hi+lo bf16 operands (fp32-class by construction, 0.40x), fp32 = torch module")
@@ -421,7 +506,8 @@ def main(argv=None):
     np.random.seed(1000 + rank)
     for epoch in range(start_epoch, start_epoch + a.epochs):
         hist, games = run_cycle(model, optimiser, sched, args, a.games_per_rank, chess960=bool(a.chess960), sync=sync,
-                                batch_size=a.batch_size, total_steps=a.total_steps, fast_inference=a.inference, train_convs=a.train_convs)
+                                batch_size=a.batch_size, total_steps=a.total_steps, fast_inference=a.inference, train_convs=a.train_convs,
+                                train_graph=(a.train_graph == "on"))
         sync_module_state(model, average_buffers=True) if world > 1 else None
         n_samples = sum(len(g["actions"]) for g in games)
         # games/RL_960_{epoch}.pt (train_RL.py:229-241 merges every worker's games into one file): rank 0 writes its games under the

@@ -135,6 +135,53 @@ def test_train_step_with_split_convolutions_matches_reference_loss_and_the_cpu_g
     assert r_sp < 5e-3 and r_mi < 5e-3
 
 
+def test_graphed_train_steps_equal_eager_steps():
+    """train_rl.GraphedStep — gradient zeroing + forward + backward of a step as one HIP-graph replay — against eager forward + backward on a twin model with the same
+    weights: the same losses and the same gradient for every batch (two eager steps on the capture stream, the capture, three replays with new batch contents, a batch
+    of another shape that drops the graph and runs eagerly, a second capture, three replays), with per-parameter gradient tensors and with GradSync's flat buffer; BatchNorm's running statistics advance
+    exactly once per step (nothing is computed twice around the capture).  Then train(graph=True) against train(graph=False) over 10 optimiser steps: same losses
+    within the divergence two eager runs show among themselves (train-mode BatchNorm over 32 samples amplifies last-bit differences of the atomics in torch's kernels)."""
+    from sigma_zero_amd import train_rl as T
+    from sigma_zero_amd.trainconv import split_convs
+    g = torch.Generator().manual_seed(5)
+    def batch(n):
+        return {"states": (torch.rand(n, 119, 8, 8, generator=g) < 0.15).float().cuda(), "actions": torch.softmax(torch.randn(n, 4672, generator=g) * 3, 1).cuda(),
+                "rewards": torch.randint(-1, 2, (n,), generator=g).float().cuda()}
+    batches = [batch(32) for _ in range(5)] + [batch(16)] + [batch(32) for _ in range(4)]
+    for use_sync in (False, True):
+        torch.manual_seed(0)
+        ref = sz.policyNN({}).cuda().train()
+        net = sz.policyNN({}).cuda().train()
+        net.load_state_dict(ref.state_dict())
+        sync = T.GradSync(net) if use_sync else None
+        with split_convs(ref), split_convs(net):
+            gs = T.GraphedStep(net, "cuda", sync)
+            for i, b in enumerate(batches):
+                ref.zero_grad()
+                loss, mse, ce = T.loss_fn(ref, b, "cuda")
+                loss.backward()
+                m2, c2 = gs.step(b)
+                assert (gs.graph is not None) == (i in (1, 2, 3, 4, 6, 7, 8, 9))          # captured at the end of the second step; dropped by the odd batch (5), captured again after 6
+                assert abs(float(m2) - float(mse)) < 1e-6 and abs(float(c2) - float(ce)) < 1e-5, (use_sync, i, float(m2), float(mse), float(c2), float(ce))
+                ga = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+                gb = torch.cat([p.grad.flatten() for p in net.parameters()]).double()
+                r = float((ga - gb).norm() / ga.norm())
+                assert r < 1e-5, (use_sync, i, r)
+        for (n1, b1), (n2, b2) in zip(ref.named_buffers(), net.named_buffers()):
+            assert torch.allclose(b1.double(), b2.double(), rtol=1e-5, atol=1e-7), n1
+        assert int(net.norm_layer.num_batches_tracked) == len(batches)
+    hist = {}
+    for kind in ("eager", "eager2", "graph"):
+        torch.manual_seed(0)
+        net = sz.policyNN({}).cuda()
+        opt, sched = T.make_optimiser(net)
+        hist[kind] = np.array(T.train(net, batches, opt, total_steps=0, lr_scheduler=sched, device="cuda", graph=(kind == "graph")))
+    noise = np.abs(hist["eager2"] - hist["eager"]).max()
+    diff = np.abs(hist["graph"] - hist["eager"]).max()
+    print("10 optimiser steps: max |loss difference| graph vs eager %.2e, eager vs eager %.2e" % (diff, noise))
+    assert len(hist["graph"]) == 10 and np.allclose(hist["graph"][0], hist["eager"][0], rtol=1e-6) and diff < max(5e-3, 10 * noise), (hist["graph"], hist["eager"])
+
+
 def test_device_batches_on_the_device_equal_dataloader_with_collate():
     """train_RL.py:14-49 (chessDataset + collatefn) vs DeviceBatches on cuda: the same batches bit for bit"""
     rng = np.random.RandomState(1)

@@ -17,6 +17,7 @@ ap.add_argument("--total-steps", type=int, default=6)
 ap.add_argument("--backend", default="nccl")
 ap.add_argument("--slots", type=int, default=0, help="board slots (default: one per game); fewer slots than games = refill + compaction")
 ap.add_argument("--train-convs", default="split", choices=["split", "torch"], help="3x3 convolutions of the train step (train_rl.train split_convs)")
+ap.add_argument("--train-graph", default="off", choices=["on", "off"], help="train_rl.train graph")
 ap.add_argument("--inference", default="fp16", choices=["fp16", "bf16", "split"], help="self-play network (run_cycle's default is fp16)")
 a = ap.parse_args()
 rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -43,7 +44,7 @@ t2 = sync_t()
 packed, aidx, aprob, rew = T.records_from_games(games)
 dl = T.DeviceBatches(packed, aidx, aprob, rew, batch_size=a.batch_size, device=dev, shuffle=True)
 t3 = sync_t()
-hist = T.train(model, dl, opt, total_steps=a.total_steps, lr_scheduler=sched, sync=sync, device=dev, split_convs=None if a.train_convs == "split" else False)
+hist = T.train(model, dl, opt, total_steps=a.total_steps, lr_scheduler=sched, sync=sync, device=dev, split_convs=None if a.train_convs == "split" else False, graph=(a.train_graph == "on"))
 t4 = sync_t()
 T.sync_module_state(model, average_buffers=True)
 t5 = sync_t()

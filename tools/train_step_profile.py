@@ -34,6 +34,9 @@ if mode in ("eager", "both"):
     print("eager fp32 step, batch %d: %.2f ms" % (Bn, timeit(step)), flush=True)
 if mode in ("graph", "both"):
     model = sz.policyNN({}).to(dev).train()
+    if os.environ.get("SZ_TRAINCONVS", "0") == "1":
+        from sigma_zero_amd.trainconv import enable_split_convs
+        enable_split_convs(model)
     opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), weight_decay=1e-4, fused=True, capturable=True)
     static = {k: v.clone() for k, v in batch.items()}
     side = torch.cuda.Stream()
