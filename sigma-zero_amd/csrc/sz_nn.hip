@@ -1010,10 +1010,10 @@ struct TowerParams {
     unsigned long long pace_base;                          // arrivals per counter before this launch
 };
 
-// STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile go to
+// STAMP = diagnostic build (tools/tower_stamps.py): s_memtime stamps around the phases of block 3 of a workgroup's second tile (its only tile at small batches) go to
 // a buffer of their own; the shipped instantiation (STAMP = false) executes no stamp.
 // tile-level stamps (second tile of a workgroup) go behind the block stamps: slot 8192 + wave*8 + k
-#define TILESTAMP(k) do { if (STAMP_ && tile == (int)(blockIdx.x + gridDim.x)) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[8192 + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
+#define TILESTAMP(k) do { if (STAMP_ && tile == stamp_tile) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[8192 + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
 #define TSTAMP(k) do { if (STAMP_ && stamp_now) { unsigned long long _t = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = _t; } } while (0)
 // WGB = 1: ONE board per workgroup, for batches of at most #CUs boards (a search of one position, the tail of a self-play run): half the latency per forward
 // of a 2-board tile with an empty half.  Same accumulation order per output element, so a board's result does not depend on the form.
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
     unsigned char* bufX = lds;
     unsigned char* bufT = lds + IMG;
     const int n_tiles = (n_boards + WGB - 1) / WGB;
+    const int stamp_tile = (int)blockIdx.x + (n_tiles > (int)gridDim.x ? (int)gridDim.x : 0);      // diagnostic builds: a workgroup's second tile, or its only one
     // zero rows of both 256-channel images (row index 128); the stem's own zero row is rewritten by stage_tile
     for (int c = threadIdx.x; c < NN_ZERO16 / 16; c += 256) {
         *(uint4*)(bufX + WGB * 64 * (NN_COUT * 2 + NN_PAD16) + c * 16) = make_uint4(0, 0, 0, 0);
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         __syncthreads();
         TILESTAMP(4);
         for (int blk = 0; blk < n_blocks; blk++) {
-            const bool stamp_now = STAMP_ && blk == 3 && tile == (int)(blockIdx.x + gridDim.x);
+            const bool stamp_now = STAMP_ && blk == 3 && tile == stamp_tile;
             TSTAMP(0);
             wave_stagger();
             auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB, E>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
@@ -1276,11 +1277,15 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1, ElemF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<0, ElemF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<1, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<2, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<3, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute((const void*)k_tower16_bf16<4, ElemBF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         attr_set = true;
     }
     const int n_cu = device_cus();
-    // one board per workgroup while every board can have a CU of its own (and no diagnostic build is asked for); flags SZ_NN_TOWER_WGB1 / _WGB2 force a form (tests)
-    const bool one = !g_tower_stamps && ((flags & SZ_NN_TOWER_WGB1) || (n_boards <= n_cu && !(flags & SZ_NN_TOWER_WGB2)));
+    // one board per workgroup while every board can have a CU of its own; flags SZ_NN_TOWER_WGB1 / _WGB2 force a form (tests)
+    const bool one = (flags & SZ_NN_TOWER_WGB1) || (n_boards <= n_cu && !(flags & SZ_NN_TOWER_WGB2));
     const int n_tiles = one ? n_boards : (n_boards + 1) / 2;
     const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu);
     unsigned long long pace_add = 0, *pace_slot = nullptr;     // the arrival counters advance only when the launch went out (a failed launch leaves them consistent)
@@ -1298,7 +1303,11 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
         }
     }
 #define TOWER_LAUNCH(M) hipLaunchKernelGGL(k_tower16_bf16<M>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
-    if (one && (flags & SZ_NN_F16))
+#define TOWER_LAUNCH1(M) hipLaunchKernelGGL((k_tower16_bf16<M, ElemBF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps)
+    if (one && g_tower_stamps && !(flags & SZ_NN_F16)) {               // diagnostic builds of the one-board form (bf16 operands): stamps, K-loop ablations 2-4
+        if (g_tower_mode == 2) TOWER_LAUNCH1(2); else if (g_tower_mode == 3) TOWER_LAUNCH1(3); else if (g_tower_mode == 4) TOWER_LAUNCH1(4); else TOWER_LAUNCH1(1);
+    }
+    else if (one && (flags & SZ_NN_F16))
         hipLaunchKernelGGL((k_tower16_bf16<0, ElemF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
     else if (one)
         hipLaunchKernelGGL((k_tower16_bf16<0, ElemBF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, (const uint16_t*)planes, prm, (uint16_t*)out, n_boards, n_blocks, (int)flags, g_tower_stamps);
@@ -1313,6 +1322,7 @@ int sz_nn_tower_bf16(const void* planes, const void* const* w_packed, const floa
     else if (g_tower_mode == 5) TOWER_LAUNCH(5);
     else TOWER_LAUNCH(1);
 #undef TOWER_LAUNCH
+#undef TOWER_LAUNCH1
     HIPCHK(hipGetLastError());
     if (pace_slot) *pace_slot += pace_add;
     return SZ_OK;

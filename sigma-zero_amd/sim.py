@@ -69,7 +69,8 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
       for every running game in game order (n_games == 1 reproduces the reference's stream; for several concurrent games the order of
       the draws necessarily differs from the reference's one-game-after-another order — generate_training_data(rng_order="reference")).
     max_plies: a game still running after that many plies is cut (result None, rewards 0); one number or one per game.
-    stats: optional dict, receives 'sims', 'nn_rows', 'plies' (work done; nn_rows = network rows evaluated)."""
+    stats: optional dict, receives 'sims', 'nn_rows', 'plies' (work done; nn_rows = network rows evaluated) and 'host_seconds' (the host's wall time per phase
+      of the ply loop: enqueue_search returns before the GPU is done, wait_search is the wait for it)."""
     import random
     if not torch.cuda.is_available():
         raise RuntimeError("self-play needs an MI355X (HIP) device: the search has no CPU fallback")
@@ -130,15 +131,26 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
             if rec["game_over"][s_]:
                 games[g]["result"] = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}[int(rec["result"][s_])]
 
+    import time
+    host = dict(compact=0.0, enqueue_search=0.0, absorb=0.0, wait_search=0.0, play_fetch=0.0, refill=0.0)     # host wall time per phase (stats["host_seconds"])
+    def lap(key, t0):
+        t1 = time.perf_counter()
+        host[key] += t1 - t0
+        return t1
     refill(range(B))
     pending = None
     while (slot_game >= 0).any():
+        t0 = time.perf_counter()
         n_rows = eng.compact() if compact else B
+        t0 = lap("compact", t0)
         eng.search()                                       # enqueues num_searches x (network + tree step); returns before the GPU is done
+        t0 = lap("enqueue_search", t0)
         if pending is not None:
             absorb(*pending)                               # previous ply's records, overlapped with this ply's search
             pending = None
+        t0 = lap("absorb", t0)
         eng.check_errors()
+        t0 = lap("wait_search", t0)
         u = np.zeros(B, dtype=np.float64)
         running = np.nonzero(slot_game >= 0)[0]
         for s_ in running[np.argsort(slot_game[running], kind="stable")]:      # draws in game order
@@ -148,12 +160,14 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
         rec = eng.fetch_ply()
         if eng.stats()["boards_error"]:
             eng.check_errors()
+        t0 = lap("play_fetch", t0)
         pending = (rec, slot_game.copy())
         work["sims"] += S * len(running); work["nn_rows"] += S * n_rows; work["plies"] += 1
         plies[slot_game[running]] += 1
         done = [int(s_) for s_ in running if (rec["game_over"][s_] and rec["active"][s_]) or plies[slot_game[s_]] >= cap[slot_game[s_]]]
         if done:
             refill(done)
+        lap("refill", t0)
         if verbose:
             print("ply %d: %d games running, %d waiting, %d network rows" % (work["plies"], int((slot_game >= 0).sum()), n_games - next_game, n_rows))
     if pending is not None:
@@ -164,6 +178,7 @@ def play_games(model, args, n_games, c960=False, scharnagl=None, uniforms=None, 
     eng.close()
     if stats is not None:
         stats.update(work)
+        stats["host_seconds"] = host
     return games
 
 

@@ -18,7 +18,8 @@ while time.time() < t_end:                       # >= 2 s of back-to-back launch
 torch.cuda.synchronize()
 modes = [int(m) for m in sys.argv[2:]] or [1]
 names = ["conv1 K loop", "epilogue1 (acc->LDS)", "barrier1", "conv2 K loop", "epilogue2 (residual)", "barrier2"]
-print("ideal K loop = 72 k-steps x 512 = 36864 MFMA cycles")
+WGB = 1 if B <= torch.cuda.get_device_properties(0).multi_processor_count else 2
+print("ideal K loop = 72 k-steps x %d = %d MFMA cycles (%d board%s per workgroup)" % (256 * WGB, 72 * 256 * WGB, WGB, "s" if WGB == 2 else ""))
 for mode in modes:
     buf = torch.zeros(256 * 4 * 16, dtype=torch.int64, device="cuda")
     N.check(N.lib().sz_nn_debug_tower_stamps(C.c_void_p(buf.data_ptr()), mode), "stamps")
@@ -41,7 +42,7 @@ for mode in modes:
     for i, n in enumerate(names):
         print("  %-22s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (n, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
     tot = s[:, 6] - s[:, 0]
-    mf = 2 * 36864 * (1.0 if mode == 5 else 66.0 / 72.0)
+    mf = 2 * 72 * 256 * WGB * (1.0 if mode == 5 else 66.0 / 72.0)
     print("  block total median %.0f cycles; MFMA-busy fraction %.3f (%.0f MFMA cycles per block)" % (np.median(tot), mf / np.median(tot), mf))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
