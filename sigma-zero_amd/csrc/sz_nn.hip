@@ -471,6 +471,87 @@ __device__ __forceinline__ void conv_kloop16(const unsigned char* lds, const uin
     }
 }
 
+// K loop of the ONE-board workgroup form (256 -> 256 channels, 3x3, persistent tower at up to #CUs boards): the same k-step order and the same MFMAs as conv_kloop16
+// — a board's result is bit-identical in both forms — but scheduled for four position tiles.  conv_kloop16 splits a k-step into two half-steps of NH position tiles; with
+// NH = 2 that is 8 MFMAs (128 cycles) between a fragment's ds_read_b128 and its use, a wait twice per k-step, and no room for the tap bookkeeping in the load-free gaps
+// (stamped: 24.2k cycles for 18.4k of MFMAs, 22.0k with every load removed; tools/tower_stamps.py 128 1 2 3 4).  Here a k-step is ONE phase of 16 MFMAs:
+//   gaps 0..3   the next k-step's four activation fragments (LDS; double-buffered by k-step parity: a whole k-step = 256 cycles ahead of their use)
+//   gaps 4..7   the weights PF = 3 k-steps ahead (L2, through the buffer descriptor)
+//   gaps 8..11  tap bookkeeping: k-step 0 reads the next tap's table entries, the last k-step forms the row addresses
+//   gap 15      one wait for everything the next k-step consumes.
+// ring_in: the first PF k-steps of weights (conv_prefetch16 under the previous epilogue).  ABL: 1 = no weight loads, 2 = no LDS reads (timing builds, results garbage).
+#ifndef NN_ONE_RING
+#define NN_ONE_RING 4                                      // weight ring of the one-board K loop: 4 or 8 slots (prefetch distance 3 or 7 k-steps of 256 cycles)
+#endif
+#ifndef NN_ONE_WHOT
+#define NN_ONE_WHOT 0                                      // timing probe: 1 = every k-step re-reads the first k-step's (cache-hot) weights; results garbage
+#endif
+template <int ABL = 0, class E = ElemBF16>
+__device__ __forceinline__ void conv_kloop16_one(const unsigned char* lds, const uint4* __restrict__ w, f32x4 (&acc)[4][4], uint4 (*ring_in)[4] /* [NN_ONE_RING - 1][4] */, const int img_off,
+                                                 const float* __restrict__ bias, const int* addr_tab) {
+    constexpr int KSTEPS = NN_COUT / 32, NI = 4, NJ = 4, NTAPS = 9, RING = NN_ONE_RING, PF = RING - 1, TOTAL_KS = NTAPS * KSTEPS;
+    constexpr int W_KSTEP_STRIDE = NN_ONE_WHOT ? 0 : 16 * 64;
+    static_assert(KSTEPS % RING == 0, "ring slots must be compile-time indices");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = lane >> 4;
+    const uint32_t wlane = (uint32_t)((wave * NI) * 64 + lane) * 16u;
+    const WSrc wr = wfrag_rsrc(w);
+    f32x4 binit[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) binit[i] = *(const f32x4*)(bias + (wave * NI + i) * 16 + 4 * kg);
+    uint4 aring[RING][NI];
+#pragma unroll
+    for (int s_ = 0; s_ < PF; s_++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) aring[s_][i] = ring_in[s_][i];
+    const int lds_base = (int)(uint32_t)(uintptr_t)lds;
+    auto abs_addr = [&](int rel) -> int {
+        int a = lds_base + img_off + rel;
+        asm volatile("" : "+v"(a));                        // see conv_kloop16: keeps base + offset + row in one VGPR, the k offset in the ds_read immediate
+        return a;
+    };
+    auto LD = [](int addr) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(uint32_t)addr; };
+    int bcur[NJ], bnxt[NJ];
+    bf16x8 bfrag[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { bnxt[j] = addr_tab[j * 64 + lane]; bcur[j] = abs_addr(bnxt[j]); }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) bfrag[0][j] = LD(bcur[j]);
+    auto tap_body = [&](const int tap, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+        for (int kc = 0; kc < KSTEPS; kc++) {
+            const int ks = tap * KSTEPS + kc;
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, aring[kc & (RING - 1)][i]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    acc[i][j] = E::mfma(a, bfrag[kc & 1][j], (FIRST && kc == 0) ? binit[i] : acc[i][j]);
+                    const int m = i * NJ + j;
+                    if (m < NJ) {
+                        if (ABL & 2) {}
+                        else if (kc + 1 < KSTEPS) bfrag[(kc + 1) & 1][m] = LD(bcur[m] + (kc + 1) * 64);
+                        else if (tap + 1 < NTAPS) bfrag[(kc + 1) & 1][m] = LD(abs_addr(bnxt[m]));
+                    } else if (m < NJ + NI) {
+                        if (!(ABL & 1) && ks + PF < TOTAL_KS)
+                            aring[(kc + PF) & (RING - 1)][m - NJ] = ld_wfrag(wr, (size_t)(ks + PF) * W_KSTEP_STRIDE, wlane + (m - NJ) * 1024);
+                    } else if (m < 2 * NJ + NI) {
+                        if (kc == 0) bnxt[m - NJ - NI] = addr_tab[((tap + 1 < NTAPS ? tap + 1 : tap) * NJ + (m - NJ - NI)) * 64 + lane];
+                        else if (kc == KSTEPS - 1) bcur[m - NJ - NI] = abs_addr(bnxt[m - NJ - NI]);
+                    } else if (m == NI * NJ - 1) {
+                        if (RING == 4) __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0): the next k-step's weights and activations (two k-steps of weight loads stay in flight)
+                        else __builtin_amdgcn_s_waitcnt(0x4078);                // vmcnt(24) lgkmcnt(0): six k-steps of weight loads stay in flight (vmcnt = simm16[15:14]:[3:0])
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    tap_body(0, std::true_type{});
+    for (int tap = 1; tap < NTAPS; tap++) tap_body(tap, std::false_type{});
+}
+
 // Byte offset of the 8-byte epilogue slot (image row, 4 channels from co) inside a 16x16x32-path image.  The 16 lanes of a ds_write_b64 group hold 16 rows
 // at one channel offset; at the 544-B pitch 8 B x (68 row) mod 128 B takes 4 values, so the store is 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT: 17 % of the
 // LDS-array cycles of the tower).  NN_EPI_NOCONFLICT=1 is a TIMING-ONLY A/B build (results garbage): the same stores and residual reads go to conflict-free
@@ -1039,11 +1120,12 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
     for (int e = threadIdx.x; e < 9 * 4 * WGB * 64; e += 256)
         addr_tab[e] = conv_tap_addr16<NN_COUT * 2 + NN_PAD16, 9, WGB>(e / (4 * WGB * 64), (e >> 6) % (4 * WGB), e & 15, (e >> 4) & 3);
     f32x4 acc[4][4 * WGB];
-    uint4 ring[4][4];                                                  // next convolution's first weight fragments, fetched under the current epilogue
+    constexpr int TRING = WGB == 1 ? NN_ONE_RING : 4;
+    uint4 ring[TRING][4];                                              // next convolution's first weight fragments, fetched under the current epilogue
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int board0 = tile * WGB;
         TILESTAMP(0);
-        conv_prefetch16<4>(prm.w[0], ring);
+        conv_prefetch16<4>(prm.w[0], (uint4 (&)[4][4])ring);
         if (prm.pace && threadIdx.x == 0) {
             // XCD-paced tile rounds: the 32 workgroups that share an XCD (blockIdx mod 8, round-robin dispatch) start every tile round together, so
             // that a layer's weights are fetched into the XCD's 4 MB L2 once per round and hit by the other 31: FETCH_SIZE 2.3-4.5e6 -> 1.43e6 KB raw
@@ -1063,7 +1145,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
         TILESTAMP(2);
         conv_kloop16<128, 9, WGB, 4, true, 0, false, E>(lds, prm.w[0], acc, false, false, ring, IMG, prm.b[0], addr_tab);  // stem (reads bufT): x = relu(bn(conv1(planes)))
         TILESTAMP(3);
-        if (n_blocks > 0) conv_prefetch16<4>(prm.w[1], ring);
+        if (n_blocks > 0) conv_prefetch16<TRING>(prm.w[1], ring);
         acc_to_lds16<WGB, E>(bufX, acc, nullptr, true);
         __syncthreads();
         TILESTAMP(4);
@@ -1073,9 +1155,9 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             wave_stagger();
             auto epi_t = [&](int i, int j) { acc_tile_to_lds16<WGB, E>(bufT, acc, i, j, true); };          // t = relu(bn1(conv1(x))); bufT is idle
             if constexpr (WGB == 2) conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab, EpiTile16<WGB, E>(bufT, acc));
-            else conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(bufX, prm.w[1 + 2 * blk], acc, false, false, ring, 0, prm.b[1 + 2 * blk], addr_tab);
+            else conv_kloop16_one<ABL, E>(bufX, prm.w[1 + 2 * blk], acc, ring, 0, prm.b[1 + 2 * blk], addr_tab);
             TSTAMP(1);
-            conv_prefetch16<4>(prm.w[2 + 2 * blk], ring);
+            conv_prefetch16<TRING>(prm.w[2 + 2 * blk], ring);
 #pragma unroll
             for (int j = (WGB == 2 ? 2 * WGB : 0); j < 4 * WGB; j++)           // second position half; the first went out under the last tap (2-board form)
 #pragma unroll
@@ -1086,9 +1168,9 @@ __global__ __launch_bounds__(256, 1) void k_tower16_bf16(const uint16_t* __restr
             wave_stagger();
             auto epi_x = [&](int i, int j) { acc_tile_residual16<WGB, E>(bufX, acc, i, j); };             // x = relu(bn2(conv2(t)) + x): own elements only, nobody reads bufX now
             if constexpr (WGB == 2) conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab, EpiResidual16<WGB, E>(bufX, acc));   // reads bufT
-            else conv_kloop16<256, 9, WGB, 4, true, ABL, false, E>(lds, prm.w[2 + 2 * blk], acc, false, false, ring, IMG, prm.b[2 + 2 * blk], addr_tab);
+            else conv_kloop16_one<ABL, E>(lds, prm.w[2 + 2 * blk], acc, ring, IMG, prm.b[2 + 2 * blk], addr_tab);
             TSTAMP(4);
-            if (blk + 1 < n_blocks) conv_prefetch16<4>(prm.w[3 + 2 * blk], ring);
+            if (blk + 1 < n_blocks) conv_prefetch16<TRING>(prm.w[3 + 2 * blk], ring);
 #pragma unroll
             for (int j = (WGB == 2 ? 2 * WGB : 0); j < 4 * WGB; j++)
 #pragma unroll
