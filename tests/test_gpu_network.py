@@ -302,6 +302,34 @@ def test_fp16_operand_network_matches_fp32_policynn():
                 assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(p0, p1) and torch.equal(v0, v1)
 
 
+def test_last_round_in_the_one_board_form_gives_the_same_bits():
+    """sz_nn_tower_bf16 above 2 x #CUs boards: a last round of at most #CUs boards is launched in the one-board form (600 boards on 256 CUs = 512 in two-board tiles + 88
+    with a CU each).  Bit-packed engine planes and NHWC planes, bf16 and f16 operands: identical to the two-board form throughout, and to the same boards evaluated alone."""
+    import random
+    from sigma_zero_amd.selfplay import SelfPlayEngine
+    torch.manual_seed(0)
+    net = sz.policyNN({}).cuda().eval()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 2 * n_cu + n_cu // 3 + 3
+    for operands in ("bf16", "fp16"):
+        fast = FastPolicyNet(net, operands=operands)
+        eng = SelfPlayEngine(fast, {"C": 2, "num_searches": 2}, B, chess960=True, planes_dtype="bits128")
+        eng.new_games([random.Random(3).randrange(960) for _ in range(B)])
+        eng.search(); eng.play(np.random.RandomState(0).random_sample(B)); eng.fetch_ply()
+        eng.begin()
+        planes = eng.planes.clone()
+        with torch.no_grad():
+            p0, v0 = (t.clone() for t in fast(planes, inference=True))
+            fast.force_wgb = N.SZ_NN_TOWER_WGB2
+            p2, v2 = (t.clone() for t in fast(planes, inference=True))
+            fast.force_wgb = 0
+            pt, vt = (t.clone() for t in fast(planes[2 * n_cu:].contiguous(), inference=True))
+        assert torch.equal(p0, p2) and torch.equal(v0, v2)
+        assert torch.equal(p0[2 * n_cu:], pt) and torch.equal(v0.reshape(-1)[2 * n_cu:], vt.reshape(-1))
+        assert float(p0.sum(1).sub(1).abs().max()) < 1e-4
+        eng.close()
+
+
 def test_split_precision_network_matches_fp32_policynn():
     """SplitPolicyNet (k_tower_split: hi + lo bf16 operands, three MFMAs per product, f32 accumulation, f32 heads) against the fp32 module —
     the reference's precision class (network.py has no reduced precision anywhere).  Tolerances are ~5x what was measured on MI355X
