@@ -663,11 +663,30 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
     // staging role: thread -> (ci = tid >> 2 of the block's 64, rows 2q, 2q+1 with q = tid & 3)
     const int sci = threadIdx.x >> 2, sq = threadIdx.x & 3;
     const int sbase = (sci >> 4) * WG_TILE_BYTES + (sci & 15) * 32;
+    // Software pipeline over the boards: the global loads of board b + 1 (x rows for the stage, gy rows for the A fragments) are issued before board b's MFMAs and
+    // consumed after them, so their latency hides behind 216 MFMAs per wave instead of standing in front of every board (49.7 -> 41.8 us at 128 boards).
+    // (Tried on top and slower, profiles/r03zzk_wgrad_variants.txt: a second stage buffer with the conversion moved behind the MFMAs and the accumulator chains
+    // interleaved by hand, 47.8 us; 64 x 32 blocks with 8 board groups — half the partial traffic, 6.8 instead of 11.6 us in the reduction — 49.7 us: the f32 -> hi / lo
+    // conversion of the operands, ~400 VALU instructions per board and wave, is what the 216 MFMAs have to hide.)
+    float4 xq[4], gq[2][2][2];
+    auto load_board = [&](int bb) {
+        const float4* src = (const float4*)(x + ((size_t)bb * 256 + cib * 64 + sci) * 64 + sq * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) xq[i] = src[i];
+#pragma unroll
+        for (int cot = 0; cot < 2; cot++)
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++) {
+                const int co = cob * 64 + (2 * wr + cot) * 16 + n;
+                const float4* g = (const float4*)(gy + ((size_t)bb * 256 + co) * 64 + (4 * kh + kg) * 8);
+                gq[cot][kh][0] = g[0]; gq[cot][kh][1] = g[1];
+            }
+    };
+    if (b0 < b1) load_board(b0);
     for (int b = b0; b < b1; b++) {
         __syncthreads();                                               // the previous board's fragments are read
         {
-            const float4* src = (const float4*)(x + ((size_t)b * 256 + cib * 64 + sci) * 64 + sq * 16);
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            const float4 v0 = xq[0], v1 = xq[1], v2 = xq[2], v3 = xq[3];
             const float rows[2][8] = {{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w}};
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
@@ -700,9 +719,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
         for (int cot = 0; cot < 2; cot++)
 #pragma unroll
             for (int kh = 0; kh < 2; kh++) {
-                const int co = cob * 64 + (2 * wr + cot) * 16 + n;
-                const float4* g = (const float4*)(gy + ((size_t)b * 256 + co) * 64 + (4 * kh + kg) * 8);
-                const float4 g0 = g[0], g1 = g[1];
+                const float4 g0 = gq[cot][kh][0], g1 = gq[cot][kh][1];
                 const float f[8] = {g0.x * sgy, g0.y * sgy, g0.z * sgy, g0.w * sgy, g1.x * sgy, g1.y * sgy, g1.z * sgy, g1.w * sgy};
                 uint32_t hh[4], ll[4];
 #pragma unroll
@@ -713,6 +730,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
                 ah[cot][kh] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
                 al[cot][kh] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
             }
+        if (b + 1 < b1) load_board(b + 1);                             // in flight under this board's MFMAs
         __syncthreads();
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
