@@ -518,6 +518,12 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(const uint16_t* __restri
 //             subnormal lo part: their error is bounded by 2^-37 of the maximum, absolutely.
 // x, y: [n_boards][256][8][8] f32;  w_stream: 72 k-steps x {hi 16 KB, lo 16 KB} from sz_nn_pack_conv_split_dev.
 // COSPLIT = 2: two workgroups per board, 128 output channels each (batches of at most #CUs / 2 boards: a batch-128 train step would otherwise leave half the chip idle)
+// Where the time goes at 128 boards (tools/trainconv_time.py with the SZ_CONV_ABL builds, back-to-back launches: 30.9 us): without the K loop 8.4 us, without the LDS stage
+// writes or with a quarter of the stores -1.4 us each, none of the three 5.5 us.  The K loop's 22.5 us for 13 us of MFMAs is the weight stream: 256 workgroups x 1.18 MB =
+// 302 MB per launch out of the L2s, 13 TB/s (64 boards on half of the CUs: 23.7 us; fetching three k-steps ahead instead of one changes nothing: bandwidth, not latency).
+#ifndef SZ_CONV_ABL
+#define SZ_CONV_ABL 0                                        // timing builds (results garbage): 1 = no K loop, 2 = no LDS stage writes, 4 = a quarter of the stores
+#endif
 template <class E, int COSPLIT>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __restrict__ x, const uint4* __restrict__ wstream, const float* __restrict__ zero_bias,
                                                                float* __restrict__ y, int n_boards, unsigned int* __restrict__ amax_bits /* optional: atomicMax of the f32 bit
@@ -585,11 +591,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
                 const int off = row * PITCH + (((c >> 3) ^ ((row >> 2) & 1)) << 4) + (c & 7) * 2;
                 const uint32_t hb = E::pack2(vv[k], 0.f) & 0xFFFFu;
                 const uint32_t lb = E::pack2(vv[k] - E::lo(hb), 0.f) & 0xFFFFu;
-                *(uint16_t*)(imgH + off) = (uint16_t)hb;
-                *(uint16_t*)(imgL + off) = (uint16_t)lb;
+                if (!(SZ_CONV_ABL & 2) || hb == 0x1234u) {
+                    *(uint16_t*)(imgH + off) = (uint16_t)hb;
+                    *(uint16_t*)(imgL + off) = (uint16_t)lb;
+                }
             }
         }
         __syncthreads();
+        if (SZ_CONV_ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{sx, sx, sx, sx};
+        } else
         split_kloop<256, WGB, true, true, 0, 9, E, NI>(lds, 0, GEO::IMG, addr_tab, wr, 0u, 0u, zero_bias, acc, ring, ct0);      // the stream restarts for the next board
         // acc tile (i, j): lane (p16, kg) holds channels (wave*4 + i)*16 + 4*kg + r, r = 0..3, of position j*16 + p16
         float* dst = y + (size_t)board * 256 * 64;
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
 #pragma unroll
             for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) dst[(size_t)((ct0 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = SCALED ? acc[i][j][r] * unscale : acc[i][j][r];
+                for (int r = 0; r < ((SZ_CONV_ABL & 4) ? 1 : 4); r++) dst[(size_t)((ct0 + i) * 16 + 4 * kg + r) * 64 + j * 16 + p16] = SCALED ? acc[i][j][r] * unscale : acc[i][j][r];
     }
 }
 
