@@ -620,10 +620,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_split_f32(const float* __res
 // torch conv weight [256 co][256 ci][3][3] f32 (device) -> the 72-k-step hi / lo fragment stream of k_conv3x3_split_f32 (device), one thread per element.
 // transposed = 1: the stream of the backward-data convolution, W'[ci][co][tap] = w[co][ci][8 - tap].  ElemF16: times 2^SP_WSCALE_LOG2.
 template <class E>
-__global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed, unsigned int* __restrict__ zero_u32) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                   // over 72 k-steps x 16 tiles x 64 lanes x 8 elements
+__global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict__ w, uint16_t* __restrict__ stream, int transposed, unsigned int* __restrict__ zero_u32,
+                                                         uint16_t* __restrict__ stream_t /* optional: the second half of the grid packs the transposed stream here, and zero_u32 has two slots */) {
+    int idx = blockIdx.x * 256 + threadIdx.x;                         // over 72 k-steps x 16 tiles x 64 lanes x 8 elements (twice with stream_t)
+    if (zero_u32 && idx == 0) { zero_u32[0] = 0u; if (stream_t) zero_u32[1] = 0u; }      // the maximum slots of the convolutions that follow on this stream
+    if (stream_t && idx >= 72 * 16 * 64 * 8) { idx -= 72 * 16 * 64 * 8; stream = stream_t; transposed = 1; }
     if (idx >= 72 * 16 * 64 * 8) return;
-    if (zero_u32 && idx == 0) *zero_u32 = 0u;                         // the maximum slot of the convolution that follows on this stream
     const int e = idx & 7, l = (idx >> 3) & 63, tile = (idx >> 9) & 15, ks = idx >> 13;
     const int tap = ks >> 3, k32 = ks & 7;
     const int co = tile * 16 + (l & 15), ci = k32 * 32 + 8 * (l >> 4) + e;
@@ -969,8 +971,18 @@ int sz_nn_conv3x3_split_f32(const float* x, const void* w_stream, const float* z
 int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* zero_u32, void* stream) {
     if (!w || !w_stream) return SZ_ERR_INVALID;
     StreamDeviceGuard _guard(stream);
-    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32);
-    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32);
+    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32, (uint16_t*)nullptr);
+    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, (int)transposed, (unsigned int*)zero_u32, (uint16_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    return SZ_OK;
+}
+// Both streams of one convolution in ONE launch (a train step packs every convolution's weights for its forward and for its backward-data pass): w_stream for the
+// forward convolution, w_stream_t for backward-data (each 72*2048*16 bytes); zero_u32: optional device uint32[2], both set to 0 (the amax_bits slots of the two convolutions).
+int sz_nn_pack_conv_split_both(const float* w, int32_t f16, void* w_stream, void* w_stream_t, void* zero_u32, void* stream) {
+    if (!w || !w_stream || !w_stream_t) return SZ_ERR_INVALID;
+    StreamDeviceGuard _guard(stream);
+    if (f16) hipLaunchKernelGGL(k_pack_conv_split<ElemF16>, dim3(2 * 72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, 0, (unsigned int*)zero_u32, (uint16_t*)w_stream_t);
+    else hipLaunchKernelGGL(k_pack_conv_split<ElemBF16>, dim3(2 * 72 * 16 * 64 * 8 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_stream, 0, (unsigned int*)zero_u32, (uint16_t*)w_stream_t);
     HIPCHK(hipGetLastError());
     return SZ_OK;
 }

@@ -32,22 +32,18 @@ OPERANDS_F16 = True          # hi + lo f16 operands with power-of-two scaling (2
 def _bufs(dev):
     key = (dev.type, dev.index)
     if key not in _scratch:
-        _scratch[key] = (torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev), torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev),
+        # forward weight stream (rewritten by every convolution), unused slot, zero bias, the weight gradient's partial sums
+        _scratch[key] = (torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev), None,
                          torch.zeros(256, dtype=torch.float32, device=dev), torch.empty(16 * 9 * 256 * 256, dtype=torch.float32, device=dev))
     return _scratch[key]
 
 
-def _conv(x, w, transposed, amax=None):
-    """y = conv3x3(x, w) (transposed: conv3x3(x, w^T flipped)) through the C ABI on x's device and current stream; x [B,256,8,8] f32.
-    amax: optional int32[1] device tensor that receives the bit pattern of max |x| (f16 operands only; the pack kernel zeroes it first)."""
+def _run_conv(x, buf, f16, amax_p):
+    """y = the convolution whose packed weight stream is `buf`, through the C ABI on x's device and current stream; x [B,256,8,8] f32."""
     x = x.contiguous()
-    fwd_buf, bwd_buf, zero, _ = _bufs(x.device)
-    buf = bwd_buf if transposed else fwd_buf
-    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    f16 = int(bool(OPERANDS_F16))
-    amax_p = C.c_void_p(amax.data_ptr()) if (amax is not None and f16) else None
-    N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(w.data_ptr()), int(transposed), f16, C.c_void_p(buf.data_ptr()), amax_p, st), "sz_nn_pack_conv_split_dev")
+    zero = _bufs(x.device)[2]
     y = torch.empty_like(x)
+    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16,
                                             amax_p, st), "sz_nn_conv3x3_split_f32")
     return y
@@ -68,31 +64,45 @@ WGRAD_KERNEL = True          # the weight gradient on the matrix cores too (f16 
 
 
 class SplitConv3x3(torch.autograd.Function):
+    """forward packs BOTH weight streams in one launch when the input wants a gradient (the backward-data stream lives in a buffer of its own until backward: 2.4 MB per
+    convolution in flight) and zeroes the two maximum slots with it; backward then is the convolution, the weight-gradient kernel and its reduction — no pack, no fill."""
+
     @staticmethod
     def forward(ctx, x, w):
-        use_wg = bool(WGRAD_KERNEL and OPERANDS_F16)
-        amax_x = torch.empty(1, dtype=torch.int32, device=x.device) if use_wg else None
-        ctx.save_for_backward(x, w, amax_x) if use_wg else ctx.save_for_backward(x, w)
-        ctx.use_wg = use_wg
-        return _conv(x, w.detach().contiguous(), False, amax_x)
+        f16 = int(bool(OPERANDS_F16))
+        use_wg = bool(WGRAD_KERNEL and f16)
+        wd = w.detach().contiguous()
+        both = bool(ctx.needs_input_grad[0])
+        amax = torch.empty(2, dtype=torch.int32, device=x.device) if use_wg else None
+        amax_p = C.c_void_p(amax.data_ptr()) if use_wg else None
+        fwd_buf = _bufs(x.device)[0]
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if both:
+            bwd_buf = torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=x.device)
+            N.check(N.lib().sz_nn_pack_conv_split_both(C.c_void_p(wd.data_ptr()), f16, C.c_void_p(fwd_buf.data_ptr()), C.c_void_p(bwd_buf.data_ptr()), amax_p, st),
+                    "sz_nn_pack_conv_split_both")
+        else:
+            bwd_buf = None
+            N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(wd.data_ptr()), 0, f16, C.c_void_p(fwd_buf.data_ptr()), amax_p, st), "sz_nn_pack_conv_split_dev")
+        ctx.save_for_backward(x, w)
+        ctx.amax, ctx.bwd_buf, ctx.f16, ctx.use_wg = amax, bwd_buf, f16, use_wg
+        return _run_conv(x, fwd_buf, f16, amax_p)
 
     @staticmethod
     def backward(ctx, gy):
-        if ctx.use_wg:
-            x, w, amax_x = ctx.saved_tensors
-        else:
-            x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         gx = gw = None
-        amax_gy = torch.empty(1, dtype=torch.int32, device=gy.device) if (ctx.use_wg and ctx.needs_input_grad[1]) else None
+        amax_gy = ctx.amax[1:] if ctx.use_wg else None
         if ctx.needs_input_grad[0]:
-            gx = _conv(gy, w.detach().contiguous(), True, amax_gy)
+            gx = _run_conv(gy, ctx.bwd_buf, ctx.f16, C.c_void_p(amax_gy.data_ptr()) if (ctx.use_wg and ctx.needs_input_grad[1]) else None)
         if ctx.needs_input_grad[1]:
             if ctx.use_wg:
                 if not ctx.needs_input_grad[0]:                    # no backward-data kernel ran: take the maximum with torch
                     amax_gy = gy.detach().abs().amax().reshape(1).view(torch.int32)
-                gw = _wgrad(gy, x, amax_gy, amax_x, w.shape)
+                gw = _wgrad(gy, x, amax_gy, ctx.amax[:1], w.shape)
             else:
                 gw = torch.nn.grad.conv2d_weight(x, w.shape, gy.contiguous(), padding=1)
+        ctx.bwd_buf = None
         return gx, gw
 
 
