@@ -250,6 +250,12 @@ int sz_nn_wgrad3x3_split_f32(const float* gy, const float* x, const void* amax_g
 int sz_nn_pack_conv_split_dev(const float* w, int32_t transposed, int32_t f16, void* w_stream, void* zero_u32 /* optional: device uint32 set to 0 = the amax_bits slot of the convolution that follows */, void* stream);
 /* both streams of one convolution in one launch: w_stream (forward) and w_stream_t (backward-data), 72*2048*16 bytes each; zero_u32: optional device uint32[2], both set to 0 */
 int sz_nn_pack_conv_split_both(const float* w, int32_t f16, void* w_stream, void* w_stream_t, void* zero_u32, void* stream);
+/* One call per direction of a training convolution.  forward: pack (both streams when w_stream_t != NULL) + y = conv3x3(x, w); amax2: optional device uint32[2],
+ * zeroed, slot 0 receives max|x|.  backward: gx = backward-data convolution of gy on w_stream_t (NULL: skipped; slot 1 of amax2 receives max|gy|), then dw = weight gradient
+ * (NULL: skipped; f16 operands only; part: scratch as in sz_nn_wgrad3x3_split_f32). */
+int sz_nn_conv3x3_train_fwd(const float* x, const float* w, int32_t f16, void* w_stream, void* w_stream_t, const float* zero256, float* y, int32_t n_boards, void* amax2, void* stream);
+int sz_nn_conv3x3_train_bwd(const float* gy, const float* x, const void* w_stream_t, const float* zero256, float* gx, void* amax2, float* part, float* dw, int32_t n_boards,
+                            int32_t f16, void* stream);
 /* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */

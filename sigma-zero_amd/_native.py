@@ -68,6 +68,8 @@ EXPORTS = {
     "sz_nn_wgrad3x3_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sz_nn_pack_conv_split_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sz_nn_pack_conv_split_both": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sz_nn_conv3x3_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sz_nn_conv3x3_train_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sz_nn_value_mlp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "sz_debug_stream_read": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sz_nn_policy_head_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_void_p]),

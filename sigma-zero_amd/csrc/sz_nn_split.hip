@@ -1006,4 +1006,30 @@ int sz_nn_wgrad3x3_split_f32(const float* gy, const float* x, const void* amax_g
     return SZ_OK;
 }
 
+// One call per direction of a training convolution (the host side of a train step is as busy as the GPU: every ctypes call and tensor allocation counts).
+// forward: pack (both streams when w_stream_t is given, else the forward one) + convolution; amax2: optional device uint32[2] = {max|x|, max|gy|} bit patterns
+// (zeroed here, slot 0 filled by this convolution, slot 1 by the backward call).
+int sz_nn_conv3x3_train_fwd(const float* x, const float* w, int32_t f16, void* w_stream, void* w_stream_t, const float* zero256, float* y, int32_t n_boards, void* amax2, void* stream) {
+    if (!x || !w || !w_stream || !zero256 || !y || n_boards <= 0) return SZ_ERR_INVALID;
+    const int rc = w_stream_t ? sz_nn_pack_conv_split_both(w, f16, w_stream, w_stream_t, amax2, stream) : sz_nn_pack_conv_split_dev(w, 0, f16, w_stream, amax2, stream);
+    if (rc != SZ_OK) return rc;
+    return sz_nn_conv3x3_split_f32(x, w_stream, zero256, y, n_boards, f16, f16 ? amax2 : nullptr, stream);
+}
+// backward: gx = backward-data convolution of gy on w_stream_t (packed by the forward call), then dw = weight gradient (f16 operands; needs amax2 from the forward call).
+// gx == NULL or dw == NULL skips that part; dw without gx needs amax2[1] = max|gy| filled by the caller.
+int sz_nn_conv3x3_train_bwd(const float* gy, const float* x, const void* w_stream_t, const float* zero256, float* gx, void* amax2, float* part, float* dw, int32_t n_boards,
+                            int32_t f16, void* stream) {
+    if (!gy || n_boards <= 0 || (!gx && !dw)) return SZ_ERR_INVALID;
+    if (gx) {
+        if (!w_stream_t || !zero256) return SZ_ERR_INVALID;
+        const int rc = sz_nn_conv3x3_split_f32(gy, w_stream_t, zero256, gx, n_boards, f16, (f16 && amax2) ? (void*)((unsigned int*)amax2 + 1) : nullptr, stream);
+        if (rc != SZ_OK) return rc;
+    }
+    if (dw) {
+        if (!x || !amax2 || !part || !f16) return SZ_ERR_INVALID;
+        return sz_nn_wgrad3x3_split_f32(gy, x, (const unsigned int*)amax2 + 1, amax2, part, dw, n_boards, stream);
+    }
+    return SZ_OK;
+}
+
 }  // extern "C"

@@ -38,28 +38,6 @@ def _bufs(dev):
     return _scratch[key]
 
 
-def _run_conv(x, buf, f16, amax_p):
-    """y = the convolution whose packed weight stream is `buf`, through the C ABI on x's device and current stream; x [B,256,8,8] f32."""
-    x = x.contiguous()
-    zero = _bufs(x.device)[2]
-    y = torch.empty_like(x)
-    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    N.check(N.lib().sz_nn_conv3x3_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], f16,
-                                            amax_p, st), "sz_nn_conv3x3_split_f32")
-    return y
-
-
-def _wgrad(gy, x, amax_gy, amax_x, wshape):
-    """dW of the convolution on hi + lo f16 operands (k_wgrad3x3_split + reduce); the two maxima are the side outputs of the forward / backward-data kernels"""
-    gy, x = gy.contiguous(), x.contiguous()
-    part = _bufs(x.device)[3]
-    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
-    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    N.check(N.lib().sz_nn_wgrad3x3_split_f32(C.c_void_p(gy.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(amax_gy.data_ptr()), C.c_void_p(amax_x.data_ptr()),
-                                             C.c_void_p(part.data_ptr()), C.c_void_p(dw.data_ptr()), x.shape[0], st), "sz_nn_wgrad3x3_split_f32")
-    return dw
-
-
 WGRAD_KERNEL = True          # the weight gradient on the matrix cores too (f16 operands only); False: torch.nn.grad.conv2d_weight (MIOpen)
 
 
@@ -71,37 +49,38 @@ class SplitConv3x3(torch.autograd.Function):
     def forward(ctx, x, w):
         f16 = int(bool(OPERANDS_F16))
         use_wg = bool(WGRAD_KERNEL and f16)
-        wd = w.detach().contiguous()
-        both = bool(ctx.needs_input_grad[0])
-        amax = torch.empty(2, dtype=torch.int32, device=x.device) if use_wg else None
-        amax_p = C.c_void_p(amax.data_ptr()) if use_wg else None
-        fwd_buf = _bufs(x.device)[0]
-        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        if both:
-            bwd_buf = torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=x.device)
-            N.check(N.lib().sz_nn_pack_conv_split_both(C.c_void_p(wd.data_ptr()), f16, C.c_void_p(fwd_buf.data_ptr()), C.c_void_p(bwd_buf.data_ptr()), amax_p, st),
-                    "sz_nn_pack_conv_split_both")
-        else:
-            bwd_buf = None
-            N.check(N.lib().sz_nn_pack_conv_split_dev(C.c_void_p(wd.data_ptr()), 0, f16, C.c_void_p(fwd_buf.data_ptr()), amax_p, st), "sz_nn_pack_conv_split_dev")
+        x, wd = x.contiguous(), w.detach().contiguous()
+        dev = x.device
+        amax = torch.empty(2, dtype=torch.int32, device=dev) if use_wg else None
+        bwd_buf = torch.empty(_STREAM_BYTES, dtype=torch.uint8, device=dev) if ctx.needs_input_grad[0] else None
+        fwd_buf, _, zero, _ = _bufs(dev)
+        y = torch.empty_like(x)
+        N.check(N.lib().sz_nn_conv3x3_train_fwd(x.data_ptr(), wd.data_ptr(), f16, fwd_buf.data_ptr(), bwd_buf.data_ptr() if bwd_buf is not None else None, zero.data_ptr(),
+                                                y.data_ptr(), x.shape[0], amax.data_ptr() if use_wg else None, torch.cuda.current_stream(dev).cuda_stream), "sz_nn_conv3x3_train_fwd")
         ctx.save_for_backward(x, w)
         ctx.amax, ctx.bwd_buf, ctx.f16, ctx.use_wg = amax, bwd_buf, f16, use_wg
-        return _run_conv(x, fwd_buf, f16, amax_p)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = gw = None
-        amax_gy = ctx.amax[1:] if ctx.use_wg else None
-        if ctx.needs_input_grad[0]:
-            gx = _run_conv(gy, ctx.bwd_buf, ctx.f16, C.c_void_p(amax_gy.data_ptr()) if (ctx.use_wg and ctx.needs_input_grad[1]) else None)
-        if ctx.needs_input_grad[1]:
-            if ctx.use_wg:
-                if not ctx.needs_input_grad[0]:                    # no backward-data kernel ran: take the maximum with torch
-                    amax_gy = gy.detach().abs().amax().reshape(1).view(torch.int32)
-                gw = _wgrad(gy, x, amax_gy, ctx.amax[:1], w.shape)
-            else:
-                gw = torch.nn.grad.conv2d_weight(x, w.shape, gy.contiguous(), padding=1)
+        gy = gy.contiguous()
+        dev = gy.device
+        want_gx, want_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = torch.empty_like(gy) if want_gx else None
+        gw = None
+        own_gw = want_gw and ctx.use_wg
+        if own_gw:
+            gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+            if not want_gx:                                         # no backward-data kernel leaves max|gy| behind: take it with torch
+                ctx.amax[1:].copy_(gy.detach().abs().amax().reshape(1).view(torch.int32))
+        if want_gx or own_gw:
+            _, _, zero, part = _bufs(dev)
+            N.check(N.lib().sz_nn_conv3x3_train_bwd(gy.data_ptr(), x.data_ptr(), ctx.bwd_buf.data_ptr() if want_gx else None, zero.data_ptr(), gx.data_ptr() if want_gx else None,
+                                                    ctx.amax.data_ptr() if ctx.use_wg else None, part.data_ptr(), gw.data_ptr() if own_gw else None, gy.shape[0], ctx.f16,
+                                                    torch.cuda.current_stream(dev).cuda_stream), "sz_nn_conv3x3_train_bwd")
+        if want_gw and not own_gw:
+            gw = torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=1)
         ctx.bwd_buf = None
         return gx, gw
 
