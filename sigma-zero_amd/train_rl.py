@@ -283,6 +283,26 @@ def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=N
     model.train()
     n_batches = sync.common_batches(len(dataloader)) if sync is not None else len(dataloader)     # identical on every rank
     graphed = GraphedStep(model, device, sync) if graph else None
+    # BatchNorm's step counters: every train-mode forward launches one `num_batches_tracked += 1` per layer (41 launches of a few microseconds in a step of ~510).
+    # They only feed momentum=None layers, which this network has none of: the counters are set aside for the loop and advanced once at its end.
+    counters = [(m, m.num_batches_tracked) for m in model.modules()
+                if on_gpu and isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None and m.momentum is not None]
+    for m, _ in counters:
+        m.num_batches_tracked = None
+    try:
+        _train_loop(model, dataloader, optimiser, total_steps, lr_scheduler, sync, device, log, start_epoch, graphed, n_batches, history)
+    finally:
+        for m, t in counters:
+            m.num_batches_tracked = t
+        if counters and history:
+            torch._foreach_add_([t for _, t in counters], len(history))
+    if not history:
+        return []
+    return [(float(m), float(c)) for m, c in torch.stack(history).cpu().tolist()]
+
+
+def _train_loop(model, dataloader, optimiser, total_steps, lr_scheduler, sync, device, log, start_epoch, graphed, n_batches, history):
+    import itertools
     for step in range(start_epoch, total_steps + 1):
         for batch in itertools.islice(iter(dataloader), n_batches):
             if graphed is not None:
@@ -305,9 +325,6 @@ def train(model, dataloader, optimiser, total_steps=6, lr_scheduler=None, sync=N
             if log:
                 log(step, float(mse.detach()), float(ce.detach()))
             history.append(torch.stack((mse.detach(), ce.detach())))  # stays on the device: no host sync per step
-    if not history:
-        return []
-    return [(float(m), float(c)) for m, c in torch.stack(history).cpu().tolist()]
 
 
 def aggregate_throughput(counts, seconds, device="cpu", force=False):

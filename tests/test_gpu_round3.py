@@ -176,6 +176,9 @@ def test_graphed_train_steps_equal_eager_steps():
         net = sz.policyNN({}).cuda()
         opt, sched = T.make_optimiser(net)
         hist[kind] = np.array(T.train(net, batches, opt, total_steps=0, lr_scheduler=sched, device="cuda", graph=(kind == "graph")))
+        # BatchNorm's step counters are set aside during the loop (41 launches per step) and advanced once at its end: the state_dict is what eager torch leaves
+        assert all(int(m.num_batches_tracked) == len(batches) for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        assert "norm_layer.num_batches_tracked" in net.state_dict()
     noise = np.abs(hist["eager2"] - hist["eager"]).max()
     diff = np.abs(hist["graph"] - hist["eager"]).max()
     print("10 optimiser steps: max |loss difference| graph vs eager %.2e, eager vs eager %.2e" % (diff, noise))

@@ -25,3 +25,12 @@ with split_convs(model):
         th = time.perf_counter() - t
         torch.cuda.synchronize(); res.append(((time.perf_counter() - t) / 60 * 1e3, th / 60 * 1e3))
 print("%s: %s ms per step (host issue %s ms)" % (ROOT, " / ".join("%.2f" % a for a, _ in res), " / ".join("%.2f" % b for _, b in res)))
+
+# train() itself (BatchNorm step counters set aside, history kept on the device) over 120 prepared batches
+model2 = sz.policyNN({}).to(dev).train()
+opt2, sched2 = T.make_optimiser(model2)
+batches = [batch] * 120
+T.train(model2, batches[:10], opt2, total_steps=0, lr_scheduler=sched2, device=dev)
+torch.cuda.synchronize(); t = time.perf_counter()
+T.train(model2, batches, opt2, total_steps=0, lr_scheduler=sched2, device=dev)
+torch.cuda.synchronize(); print("%s: train() over 120 steps: %.2f ms per step" % (ROOT, (time.perf_counter() - t) / 120 * 1e3))
