@@ -869,8 +869,27 @@ extern "C" {
 
 }  // extern "C"
 
+static int launch_split_one(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream,
+                            const SplitHeadsParams* heads);
+// As in sz_nn_tower_bf16: above 2 x #CUs boards a last round of at most #CUs boards is a launch of its own in the one-board form (768 boards: 512 in two-board tiles + 256
+// with a CU each instead of a second two-board round on half of the CUs); per-board results are identical in both forms.
 static int launch_split(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream,
                         const SplitHeadsParams* heads) {
+    const int n_cu = device_cus(), rem = n_boards % (2 * n_cu);
+    if (n_boards > 2 * n_cu && rem > 0 && rem <= n_cu && !(flags & (SZ_NN_SPLIT_WGB1 | SZ_NN_SPLIT_WGB2)) && !g_split_stamps) {
+        const int head = n_boards - rem;
+        const size_t plane_bytes = (flags & SZ_NN_IN_BITS) ? 64 * sizeof(uint4) : (size_t)64 * 128 * 2;
+        const int rc = launch_split_one(planes, w_stream, bias, n_blocks, out, head, flags | SZ_NN_SPLIT_WGB2, stream, heads);
+        if (rc != SZ_OK) return rc;
+        SplitHeadsParams hp2;
+        if (heads) { hp2 = *heads; hp2.probs += (size_t)head * 4672; hp2.v1_out += (size_t)head * 64; }
+        return launch_split_one((const unsigned char*)planes + head * plane_bytes, w_stream, bias, n_blocks, out ? out + (size_t)head * 64 * 256 : nullptr, rem,
+                                flags | SZ_NN_SPLIT_WGB1, stream, heads ? &hp2 : nullptr);
+    }
+    return launch_split_one(planes, w_stream, bias, n_blocks, out, n_boards, flags, stream, heads);
+}
+static int launch_split_one(const void* planes, const void* w_stream, const float* bias, int32_t n_blocks, float* out, int32_t n_boards, int32_t flags, void* stream,
+                            const SplitHeadsParams* heads) {
     static bool attr_flags[NN_MAX_DEVICES] = {};
     bool& attr_set = attr_flags[current_device_slot()];
     if (!attr_set) {

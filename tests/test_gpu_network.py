@@ -304,15 +304,17 @@ def test_fp16_operand_network_matches_fp32_policynn():
 
 def test_last_round_in_the_one_board_form_gives_the_same_bits():
     """sz_nn_tower_bf16 above 2 x #CUs boards: a last round of at most #CUs boards is launched in the one-board form (600 boards on 256 CUs = 512 in two-board tiles + 88
-    with a CU each).  Bit-packed engine planes and NHWC planes, bf16 and f16 operands: identical to the two-board form throughout, and to the same boards evaluated alone."""
+    with a CU each).  Bit-packed engine planes; bf16, f16 and split-precision (k_tower_split with fused heads) networks: identical to the two-board form throughout, and to the same boards evaluated alone."""
     import random
     from sigma_zero_amd.selfplay import SelfPlayEngine
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     B = 2 * n_cu + n_cu // 3 + 3
-    for operands in ("bf16", "fp16"):
-        fast = FastPolicyNet(net, operands=operands)
+    from sigma_zero_amd.fastnet import SplitPolicyNet
+    for operands in ("bf16", "fp16", "split"):
+        fast = SplitPolicyNet(net) if operands == "split" else FastPolicyNet(net, operands=operands)
+        wgb2 = N.SZ_NN_SPLIT_WGB2 if operands == "split" else N.SZ_NN_TOWER_WGB2
         eng = SelfPlayEngine(fast, {"C": 2, "num_searches": 2}, B, chess960=True, planes_dtype="bits128")
         eng.new_games([random.Random(3).randrange(960) for _ in range(B)])
         eng.search(); eng.play(np.random.RandomState(0).random_sample(B)); eng.fetch_ply()
@@ -320,7 +322,7 @@ def test_last_round_in_the_one_board_form_gives_the_same_bits():
         planes = eng.planes.clone()
         with torch.no_grad():
             p0, v0 = (t.clone() for t in fast(planes, inference=True))
-            fast.force_wgb = N.SZ_NN_TOWER_WGB2
+            fast.force_wgb = wgb2
             p2, v2 = (t.clone() for t in fast(planes, inference=True))
             fast.force_wgb = 0
             pt, vt = (t.clone() for t in fast(planes[2 * n_cu:].contiguous(), inference=True))

@@ -457,9 +457,14 @@ def test_train_rl_main_two_ranks_on_one_gpu(tmp_path):
     assert len(games["states"]) == len(games["actions"]) == len(games["rewards"]) == len(games["colours"]) > 0
     assert tuple(games["states"][0].shape) == (119, 8) and games["states"][0].dtype == torch.uint8
     # --merge-games: the reference's single games file (train_RL.py:229-241) = rank 0's samples followed by rank 1's
-    out = subprocess.run([("29534" if c == "29533" else c) for c in cmd] + ["--merge-games", "--games-dir", str(tmp_path / "games2"), "--save-dir", str(tmp_path / "saves2"), "--log-dir", ""],
+    # ... and, in the same second run, --train-graph on: forward + backward of a step as one HIP-graph replay, all gradient buckets reduced over the two ranks after it
+    out = subprocess.run([("29534" if c == "29533" else c) for c in cmd] + ["--merge-games", "--games-dir", str(tmp_path / "games2"), "--save-dir", str(tmp_path / "saves2"),
+                                                                            "--log-dir", str(tmp_path / "logs2"), "--train-graph", "on"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    steps2 = [json.loads(l) for l in open(tmp_path / "logs2" / "RL_train.jsonl")]
+    assert len(steps2) == 7 and abs(steps2[0]["loss"] - steps[0]["loss"]) < 1e-4 * abs(steps[0]["loss"])          # the same games, the same first batch
+    assert all(abs(a["loss"] - b["loss"]) < 5e-2 * abs(b["loss"]) for a, b in zip(steps2, steps)), (steps2, steps)   # later steps: within what two eager runs differ by
     merged = torch.load(tmp_path / "games2" / "RL_960_1.pt", weights_only=True)
     assert len(merged["states"]) == len(merged["actions"]) == len(merged["rewards"]) == len(merged["colours"]) == 150
     assert not (tmp_path / "games2" / "RL_960_1.rank1.pt").exists()
