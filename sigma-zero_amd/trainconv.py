@@ -3,16 +3,19 @@ fp32's accuracy: hi + lo f16 operands (22 bits of mantissa), three MFMAs per pro
 power-of-two scaling: the weights are packed times 2^10, every board (forward / backward-data) or the whole tensor (weight gradient) is scaled so that its largest
 magnitude lands in [2^11, 2^12), the output is scaled back — gradients of 1e-7 and activations of 1e+3 are treated alike.
   forward, backward-data  k_conv3x3_split_f32: the inference tower's K loop, one board per workgroup (two workgroups per board at up to #CUs/2 boards); backward-data is
-                          the same convolution of the output gradient with the weights transposed and flipped; the weights are packed on the device every step;
+                          the same convolution of the output gradient with the weights transposed and flipped; both weight streams are packed on the device by one
+                          launch per convolution and step;
   weight gradient         k_wgrad3x3_split + k_wgrad_reduce: the MFMA's reduction dimension is the position (a lane's 8 k-elements = one board row), the x block is
-                          staged per board in LDS in three column-shifted copies, 16 board groups write partial sums that a second kernel adds.
-MIOpen's fp32 kernels take 90-105 us (forward), 216 us (backward) per convolution at batch 128 — 78 % of an optimiser step; these take 42 us and 109 us.
+                          staged per board in LDS in three column-shifted copies (the next board's loads in flight under this board's MFMAs), 16 board groups write
+                          partial sums that a second kernel adds.
+One call through the C ABI per direction (sz_nn_conv3x3_train_fwd / _bwd): the host's time per convolution counts as much as the GPU's here.
+MIOpen's fp32 kernels take 90-105 us (forward), 216 us (backward) per convolution at batch 128 — 78 % of an optimiser step; these take 41 us and 95 us.
 
     with split_convs(model):            # or enable_split_convs(model) / disable_split_convs(model)
         loss, mse, ce = train_rl.loss_fn(model, batch, device); loss.backward()
 
 `train_rl.train` switches it on by default for an fp32 model on a GPU (`split_convs=False` / `--train-convs torch`: MIOpen).  Measured at batch 128
-(tools/trainconv_probe.py, profiles/r03zm_trainconv_probe.txt): optimiser step 12.9 -> 8.0-8.6 ms; forward / input gradient / weight gradient of one convolution
+(tools/trainconv_probe.py, profiles/r03zze_trainconv_probe.txt, r03zzr_train_loop_same_box_ab_counters.txt): optimiser step 12.9 -> 7.1-7.6 ms; forward / input gradient / weight gradient of one convolution
 5.0e-7 / 5.1e-7 / 2.7e-7 relative L2 from fp64 (torch fp32: 4.9e-7 / 5.1e-7 / 2.5e-7), also on inputs scaled by 1e3 or 1e-6; whole-network gradient 3.45e-3 from an fp64
 step (MIOpen's fp32 step: 3.37e-3; the 39 train-mode BatchNorms amplify every rounding).  OPERANDS_F16 = False selects hi + lo bf16 operands for forward / backward-data
 (16 bits: 4.5e-6 per convolution, gradient 1.1e-2) with torch's weight gradient; WGRAD_KERNEL = False keeps torch's weight gradient.
