@@ -256,6 +256,13 @@ int sz_nn_pack_conv_split_both(const float* w, int32_t f16, void* w_stream, void
 int sz_nn_conv3x3_train_fwd(const float* x, const float* w, int32_t f16, void* w_stream, void* w_stream_t, const float* zero256, float* y, int32_t n_boards, void* amax2, void* stream);
 int sz_nn_conv3x3_train_bwd(const float* gy, const float* x, const void* w_stream_t, const float* zero256, float* gx, void* amax2, float* part, float* dw, int32_t n_boards,
                             int32_t f16, void* stream);
+/* Train-mode BatchNorm2d + optional skip connection + ReLU in one launch per direction (network.py:62-83 under train_RL.py:103-122; csrc/sz_train.hip):
+ * y = relu(bn(x) [+ residual]) with batch statistics over (boards, 8, 8) per channel, running statistics updated in place with `momentum` (NULL: not tracked),
+ * save_mean / save_invstd [channels] kept for backward.  x, y, residual, gy, dx, dres: device [n_boards, channels, 8, 8] f32; dres NULL without a residual. */
+int sz_bn_act_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                        float* y, float* save_mean, float* save_invstd, int32_t n_boards, int32_t channels, void* stream);
+int sz_bn_act_train_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* save_mean, const float* save_invstd, float* dx, float* dres,
+                        float* dgamma, float* dbeta, int32_t n_boards, int32_t channels, void* stream);
 /* value MLP alone (network.py:162-172): v1 [n_boards,64] f32 = relu(bn(conv_v1(x))) -> fc_v1 -> ReLU -> fc_v2 -> tanh -> value [n_boards] */
 int sz_nn_value_mlp(const float* v1, const float* fc1_w_t, const float* fc1_b, const float* fc2_w, float fc2_b, float* value, int32_t n_boards, void* stream);
 /* diagnostic only: device buffer of 256*4*16 uint64; sz_nn_tower_split then launches its stamped build (tools/split_stamps.py); NULL = shipped kernel */

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 DEFAULT_LIB = os.path.join(PKG, "libsigmazero_hip.so")
 LIB = os.environ.get("SIGMAZERO_LIB") or DEFAULT_LIB      # SIGMAZERO_LIB: A/B runs of two builds of the library on one GPU box
-SOURCES = ["sz_engine.hip", "sz_nn.hip", "sz_nn_split.hip", "sz_host.cpp"]
+SOURCES = ["sz_engine.hip", "sz_nn.hip", "sz_nn_split.hip", "sz_train.hip", "sz_host.cpp"]
 HEADERS = [os.path.join(CSRC, "sz_chess.h"), os.path.join(CSRC, "sz_nn_common.h"), os.path.join(PKG, "..", "include", "sigmazero.h")]
 # -ffp-contract=off: the UCB / prior arithmetic must round exactly like the reference's torch ops
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-int-to-pointer-cast"]
