@@ -682,8 +682,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
     // Software pipeline over the boards: the global loads of board b + 1 (x rows for the stage, gy rows for the A fragments) are issued before board b's MFMAs and
     // consumed after them, so their latency hides behind 216 MFMAs per wave instead of standing in front of every board (49.7 -> 41.8 us at 128 boards).
     // (Tried on top and slower, profiles/r03zzk_wgrad_variants.txt: a second stage buffer with the conversion moved behind the MFMAs and the accumulator chains
-    // interleaved by hand, 47.8 us; 64 x 32 blocks with 8 board groups — half the partial traffic, 6.8 instead of 11.6 us in the reduction — 49.7 us: the f32 -> hi / lo
-    // conversion of the operands, ~400 VALU instructions per board and wave, is what the 216 MFMAs have to hide.)
+    // interleaved by hand, 47.8 us; 64 x 32 blocks with 8 board groups — half the partial traffic, 6.8 instead of 11.6 us in the reduction — 49.7 us; operands read pre-split from the
+    // convolutions instead of converted here, chains interleaved by hand: no change.)
     float4 xq[4], gq[2][2][2];
     auto load_board = [&](int bb) {
         const float4* src = (const float4*)(x + ((size_t)bb * 256 + cib * 64 + sci) * 64 + sq * 16);
