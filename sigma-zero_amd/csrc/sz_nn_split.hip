@@ -646,8 +646,10 @@ __global__ __launch_bounds__(256) void k_pack_conv_split(const float* __restrict
 //   144 accumulator registers) and writes ONE partial, [KG][tap][co][ci]; k_wgrad_reduce sums the KG partials into dW [co][ci][tap].
 //   gy fragments (A operand, rows = co) come straight from global memory (a lane's 8 floats are contiguous); the x block is staged per board in LDS as f16 hi / lo in
 //   three column-shifted copies (dx = -1, 0, +1) with a zero row above and below, so that every tap's B fragment is one aligned ds_read_b128:
-//   Xs[dx][ci tile][row -1..8][ci 0..15]{hi 16 B, lo 16 B}, row pitch 528 B (slot 2*ci + row: conflict-free for the ds_read_b128 lane groups).
-#define WG_ROWPITCH 528
+//   Xs[dx][ci tile][row -1..8]{hi: ci 0..15 x 16 B, lo: ci 0..15 x 16 B}, row pitch 512 B: the 16 lanes of a ds_read_b128 / ds_write_b128 group touch 16 consecutive
+//   16-byte slots of one row.  SQ_LDS_BANK_CONFLICT = 0 (rocprofv3 --pmc on tools/wgrad_time.py; at row pitches 528 / 544 / 576 / 640 B: 45 % of the LDS-active cycles,
+//   at the same launch time).
+#define WG_ROWPITCH 512
 #define WG_TILE_BYTES (10 * WG_ROWPITCH)
 #define WG_LDS_BYTES (3 * 4 * WG_TILE_BYTES)
 __device__ __forceinline__ float pow2_from_amax_bits(unsigned int bits, int target_log2, int* k_out) {
@@ -676,9 +678,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int t = 0; t < 9; t++) acc[a][c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging role: thread -> (ci = tid >> 2 of the block's 64, rows 2q, 2q+1 with q = tid & 3)
-    const int sci = threadIdx.x >> 2, sq = threadIdx.x & 3;
-    const int sbase = (sci >> 4) * WG_TILE_BYTES + (sci & 15) * 32;
+    // staging role: thread -> (ci = lane of the block's 64, rows 2q, 2q+1 with q = wave): the 16 lanes of a ds_write_b128 group write 16 consecutive 16-byte slots of one
+    // row (with ci = tid >> 2, q = tid & 3 a group's lanes were spread over four rows)
+    const int sci = threadIdx.x & 63, sq = threadIdx.x >> 6;
+    const int sbase = (sci >> 4) * WG_TILE_BYTES + (sci & 15) * 16;
     // Software pipeline over the boards: the global loads of board b + 1 (x rows for the stage, gy rows for the A fragments) are issued before board b's MFMAs and
     // consumed after them, so their latency hides behind 216 MFMAs per wave instead of standing in front of every board (49.7 -> 41.8 us at 128 boards).
     // (Tried on top and slower, profiles/r03zzk_wgrad_variants.txt: a second stage buffer with the conversion moved behind the MFMAs and the accumulator chains
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
                     }
                     unsigned char* dst = lds + dxi * 4 * WG_TILE_BYTES + sbase + row * WG_ROWPITCH;
                     *(uint4*)dst = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-                    *(uint4*)(dst + 16) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                    *(uint4*)(dst + 256) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
                 }
             }
         }
@@ -748,22 +751,33 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_split(const float* __restri
             }
         if (b + 1 < b1) load_board(b + 1);                             // in flight under this board's MFMAs
         __syncthreads();
+        // 36 groups (k half, ci tile, tap) of two fragment reads + six MFMAs.  The fragments are fetched WG_AHEAD groups ahead into a register ring and the schedule is
+        // pinned: left to itself hipcc issues a group's two ds_read_b128 right in front of its MFMAs and waits for them — the LDS latency stood exposed in front of every
+        // group of 96 MFMA cycles (24.5 us of MFMA loop for 13 us of MFMAs; tools/wgrad_time.py with the WG_ABL builds).
+        constexpr int WG_AHEAD = 2, NGRP = 36;
+        bf16x8 bh[WG_AHEAD + 1], bl[WG_AHEAD + 1];
+        auto fetch = [&](int g) {
+            const int kh = g / 18, cit = (g / 9) & 1, tap = g % 9, dy = tap / 3 - 1, dxi = tap % 3;
+            const unsigned char* src = lds + (dxi * 4 + 2 * wc + cit) * WG_TILE_BYTES + (4 * kh + kg + dy + 1) * WG_ROWPITCH + n * 16;
+            bh[g % (WG_AHEAD + 1)] = *(const bf16x8*)src; bl[g % (WG_AHEAD + 1)] = *(const bf16x8*)(src + 256);
+        };
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++)
+        for (int g = 0; g < WG_AHEAD; g++) fetch(g);
 #pragma unroll
-            for (int cit = 0; cit < 2; cit++)
+        for (int g = 0; g < NGRP; g++) {
+            if (g + WG_AHEAD < NGRP) fetch(g + WG_AHEAD);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int kh = g / 18, cit = (g / 9) & 1, tap = g % 9, sl = g % (WG_AHEAD + 1);
 #pragma unroll
-                for (int tap = 0; tap < 9; tap++) {
-                    const int dy = tap / 3 - 1, dxi = tap % 3;
-                    const unsigned char* src = lds + (dxi * 4 + 2 * wc + cit) * WG_TILE_BYTES + (4 * kh + kg + dy + 1) * WG_ROWPITCH + n * 32;
-                    const bf16x8 bh = *(const bf16x8*)src, bl = *(const bf16x8*)(src + 16);
-#pragma unroll
-                    for (int cot = 0; cot < 2; cot++) {
-                        acc[cot][cit][tap] = E::mfma(ah[cot][kh], bh, acc[cot][cit][tap]);
-                        acc[cot][cit][tap] = E::mfma(al[cot][kh], bh, acc[cot][cit][tap]);
-                        acc[cot][cit][tap] = E::mfma(ah[cot][kh], bl, acc[cot][cit][tap]);
-                    }
-                }
+            for (int cot = 0; cot < 2; cot++) {
+                acc[cot][cit][tap] = E::mfma(ah[cot][kh], bh[sl], acc[cot][cit][tap]);
+                acc[cot][cit][tap] = E::mfma(al[cot][kh], bh[sl], acc[cot][cit][tap]);
+                acc[cot][cit][tap] = E::mfma(ah[cot][kh], bl[sl], acc[cot][cit][tap]);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // the partial: [kgrp][tap][co][ci]; D layout: lane column n = ci, rows 4*kg + r = co
 #pragma unroll
