@@ -146,12 +146,14 @@ def test_split_precision_network_searches_like_fp32():
 
 
 # ------------------------------------------------------------------------------------------------ 3. ragged self-play: refill + compaction
-@pytest.mark.parametrize("kind,n_games,n_slots", [("fast", 12, 5), ("split", 12, 5), ("split", 300, 130), ("fast", 300, 130), ("fp16", 300, 130)])
+@pytest.mark.parametrize("kind,n_games,n_slots", [("fast", 12, 5), ("split", 12, 5), ("split", 300, 130), ("fast", 300, 130), ("fp16", 300, 130),
+                                                   ("fp16", 700, 300), ("split", 700, 300)])
 def test_refill_and_compaction_give_identical_per_game_records(kind, n_games, n_slots):
     """sim.py:102-123 plays exactly num_games games.  The product runs them on fewer board slots than games (slot refill) and evaluates
     only the boards that still play (compaction); per-game records must be bit-identical to the plain run (one slot per game, no
     compaction), because a game's results do not depend on what runs beside it.  All MFMA networks (bf16 / f16 operands, split precision); the
-    300-game cases also cross from two boards per workgroup (300 boards) to one (130 and fewer)."""
+    300-game cases also cross from two boards per workgroup (300 boards) to one (130 and fewer); the 700-game cases run the plain side above 2 x #CUs boards, where
+    the towers' last round goes out as a launch of its own in the one-board form."""
     from sigma_zero_amd.fastnet import SplitPolicyNet
     torch.manual_seed(0)
     net = sz.policyNN({}).cuda().eval()
