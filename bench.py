@@ -23,6 +23,8 @@ One JSON line is printed by rank 0.  Extra objects:
                 simulations/s, launch duration of k_tower_split by HIP events, algorithmic AND issued MFMA fraction of the 2.5 PFLOP/s peak (N=1 only)
   fp16_config   the same workload on f16 operands (the product API's default self-play network; one timed ply, N=1 only)
   parity_config simulations/s of the same boards-per-GPU with the fp32 network the reference uses (bounded sample, N=1 only)
+  train_step    the optimiser step of the same loop (train_RL.py:103-122, batch 128, synthetic batches): ms per step with the matrix-core convolutions + fused
+                BatchNorm (train_rl.train's default) and with torch / MIOpen fp32 beside it (a few seconds, N=1 only)
 `--gpus N` with N > 1 outside a launcher (no RANK in the environment) starts N ranks itself (torch.distributed.run on 127.0.0.1) before any GPU call,
 as the reference spawns its own self-play workers (train_RL.py:215-227); under a launcher WORLD_SIZE must equal --gpus.
   cpu_baseline  the oracle (reference algorithm restated on the CPU: one leaf per step, per-game pointer tree,
@@ -255,6 +257,37 @@ def fp16_sample(dev, B, S, chess960):
             "sample": "%d boards x num_searches=%d, one ply after one warm-up ply, %d simulations in %.2f s" % (B, S, sims, dt),
             "tower_launch_ms": ms, "tower_frac_of_mfma_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "fidelity": "64/64 test positions with the fp32 network's exact visit counts at 100 and 800 searches (bf16: 61-62/64); tests/test_gpu_train_and_precision.py"}
+
+
+def train_step_sample(dev, batch=128, steps=40):
+    """The optimiser step of the same loop (train_RL.py:103-122: fp32 forward + backward + Adam at the reference's batch size; configs[3]'s other half) on synthetic
+    batches: ms per step with the matrix-core convolutions + fused BatchNorm (train_rl.train's default) and with torch / MIOpen fp32.  Side measurement, a few seconds."""
+    import sigma_zero_amd as sz
+    from sigma_zero_amd import train_rl as T
+    from sigma_zero_amd.trainconv import split_convs
+    import contextlib
+    g = torch.Generator(device=dev).manual_seed(1)
+    b = {"states": (torch.rand(batch, 119, 8, 8, device=dev, generator=g) < 0.15).float(), "actions": torch.softmax(torch.randn(batch, 4672, device=dev, generator=g) * 3, 1),
+         "rewards": torch.randint(-1, 2, (batch,), device=dev, generator=g).float()}
+    out = {"unit": "ms per optimiser step", "batch": batch, "steps": steps, "dtype": "f32 (convolutions: hi + lo f16 operands on the matrix cores, f32 accumulate)",
+           "data": "synthetic"}
+    for name, ctx in (("torch_miopen_fp32", contextlib.nullcontext), ("value", split_convs)):
+        torch.manual_seed(0)
+        model = sz.policyNN({}).to(dev).train()
+        opt, sched = T.make_optimiser(model)
+        with (ctx(model) if ctx is split_convs else ctx()):
+            def step():
+                opt.zero_grad(); loss, _, _ = T.loss_fn(model, b, dev); loss.backward(); opt.step(); sched.step()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            out[name] = (time.perf_counter() - t0) / steps * 1e3
+    out["samples_per_s"] = batch / out["value"] * 1e3
+    return out
 
 
 def self_launch(n, argv):
@@ -498,6 +531,11 @@ def main():
                 out["parity_config"] = parity_config_sample(dev, B, a.chess960)
             except Exception as ex:                     # noqa: BLE001
                 out["parity_config"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
+        if not a.no_split and world == 1 and fast:
+            try:
+                out["train_step"] = train_step_sample(dev)
+            except Exception as ex:                     # noqa: BLE001
+                out["train_step"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (bounded ~15 s sample)
             try:
                 out["cpu_baseline"] = cpu_baseline()
