@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-config", action="store_true", help="skip the fp32-network sample (`parity_config`)")
     ap.add_argument("--no-split", action="store_true", help="skip the reference-precision run on the matrix cores (`roofline_split`)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the optimiser-step side sample (`train_step`)")
     ap.add_argument("--split-plies", type=int, default=3, help="timed plies of the `roofline_split` run (after one warm-up ply)")
     ap.add_argument("--no-kernel-events", action="store_true")
     a = ap.parse_args()
@@ -531,7 +532,7 @@ def main():
                 out["parity_config"] = parity_config_sample(dev, B, a.chess960)
             except Exception as ex:                     # noqa: BLE001
                 out["parity_config"] = {"value": None, "error": "%s: %s" % (type(ex).__name__, ex)}
-        if not a.no_split and world == 1 and fast:
+        if not a.no_train_step and world == 1 and fast:
             try:
                 out["train_step"] = train_step_sample(dev)
             except Exception as ex:                     # noqa: BLE001

@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG && mkdir -p /tmp/prof_$TAG
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import json, sigma_zero_amd.build as b; print(json.dumps({g: b.source_hash(g) for g in ('tower', 'split', 'tree')}))" > $OUT/${TAG}_source_hash.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-config --split-plies 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-config --no-train-step --split-plies 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
 cp $(find /tmp/prof_$TAG/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
 echo "stats done"
 for spec in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU"; do
